@@ -1,0 +1,247 @@
+/*
+ * mrt_hip.h — C-ABI of the MI355X (gfx950) batch ray-cast backend.
+ *
+ * This is the drop-in boundary: everything the reference's `GPURayCaster`
+ * (src/gpu/gpu_ray_caster.h:50-136) does through Godot's RenderingDevice is
+ * reachable through these entry points.  `RayDispatcher`
+ * (src/dispatch/ray_dispatcher.h:74-79,124-356) keeps calling a caster-shaped
+ * C++ object (messyerraytracer_amd/csrc/host/gpu_ray_caster.hpp) that forwards
+ * here.  Plain pointers and sizes only; no C++/torch types; never throws.
+ *
+ * All structs are natural C layout == GLSL std430 of the reference
+ * (src/api/gpu_types.h:44-126, src/gpu/gpu_structs.h:41-47) or the reference's
+ * host PODs at precision=single (src/core/ray.h:25-98,
+ * src/core/intersection.h:16-61, src/core/triangle.h:22-51).
+ */
+#ifndef MRT_HIP_H_
+#define MRT_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRT_VERSION_MAJOR 0
+#define MRT_VERSION_MINOR 1
+
+/* ---- status codes (no exceptions cross the boundary; reference convention:
+ *      tools/lint.py rule no-exceptions, gpu_ray_caster.cpp:76-115) ---------- */
+enum {
+	MRT_OK = 0,
+	MRT_ERR_INVALID = 1,      /* null pointer / bad argument / bad struct_size   */
+	MRT_ERR_NO_DEVICE = 2,    /* no gfx950 device at that ordinal                */
+	MRT_ERR_HIP = 3,          /* a HIP runtime call failed; see mrt_last_error   */
+	MRT_ERR_NO_SCENE = 4,     /* cast before upload_scene (is_available()==false) */
+	MRT_ERR_PENDING = 5,      /* submit while a dispatch is pending (cpp:538)    */
+	MRT_ERR_NOT_PENDING = 6,  /* collect without submit                          */
+	MRT_ERR_OOM = 7,
+	MRT_ERR_UNSUPPORTED = 8,
+	MRT_ERR_BAD_BVH = 9       /* BVH failed host-side validation before upload   */
+};
+
+/* ---- device PODs -------------------------------------------------------- */
+
+/* GPURayPacked, src/api/gpu_types.h:65-69 */
+typedef struct mrt_ray32 {
+	float origin[3];    float t_max;
+	float direction[3]; float t_min;
+} mrt_ray32;
+
+/* GPUIntersectionPacked, src/api/gpu_types.h:87-92; prim_id == -1 => miss */
+typedef struct mrt_hit32 {
+	float t;          int32_t prim_id;
+	float bary_u;     float bary_v;
+	float normal[3];  uint32_t hit_layers;
+} mrt_hit32;
+
+/* GPUTrianglePacked, src/api/gpu_types.h:44-50 */
+typedef struct mrt_tri64 {
+	float v0[3];     uint32_t id;
+	float edge1[3];  uint32_t layers;
+	float edge2[3];  float pad2;
+	float normal[3]; float pad3;
+} mrt_tri64;
+
+/* tinybvh::BVH::BVHNode (thirdparty/tinybvh/tiny_bvh.h:857-866) ==
+ * GPUBVHNodePacked (src/api/gpu_types.h:122-126).  tri_count>0 => leaf,
+ * left_first = first slot in prim_idx[]; else children are the adjacent pair
+ * left_first, left_first+1.  Node 0 is the root, node 1 is an unused hole. */
+typedef struct mrt_bvh_node32 {
+	float aabb_min[3]; uint32_t left_first;
+	float aabb_max[3]; uint32_t tri_count;
+} mrt_bvh_node32;
+
+/* GPUBVHNodeWide, src/gpu/gpu_structs.h:41-47 (Aila-Laine dual-AABB node).
+ * count>0 => that child is a leaf and idx is its first triangle slot in the
+ * (leaf-ordered) device triangle array; count==0 => idx is a wide-node index. */
+typedef struct mrt_bvh_node_wide64 {
+	float left_min[3];  uint32_t left_idx;
+	float left_max[3];  uint32_t right_idx;
+	float right_min[3]; uint32_t left_count;
+	float right_max[3]; uint32_t right_count;
+} mrt_bvh_node_wide64;
+
+/* ---- host PODs of the reference (precision=single) ---------------------- */
+
+/* Ray, src/core/ray.h:25-51 (60 B).  Only origin/direction/t_min/t_max are
+ * consumed (gpu_ray_caster.cpp:643-650). */
+typedef struct mrt_host_ray60 {
+	float origin[3];
+	float direction[3];
+	float inv_direction[3];
+	int32_t dir_sign[3];
+	float t_min, t_max;
+	uint32_t flags;
+} mrt_host_ray60;
+
+/* Intersection, src/core/intersection.h:16-40 (44 B); miss: prim_id=UINT32_MAX,
+ * t=FLT_MAX, u=v=0, hit_layers=0, position/normal untouched by set_miss(). */
+typedef struct mrt_host_hit44 {
+	float t;
+	float position[3];
+	float normal[3];
+	float u, v;
+	uint32_t prim_id;
+	uint32_t hit_layers;
+} mrt_host_hit44;
+
+/* Triangle, src/core/triangle.h:22-39 (80 B) */
+typedef struct mrt_host_tri80 {
+	float v0[3], v1[3], v2[3];
+	float edge1[3], edge2[3], normal[3];
+	uint32_t id, layers;
+} mrt_host_tri80;
+
+/* Camera for the on-device primary-ray grid: the formula of
+ * RayTracerDebug::cast_debug_rays, src/godot/raytracer_debug.cpp:572-596.
+ * mrt_camera_look() fills basis + half extents on the host exactly as :573-583. */
+typedef struct mrt_camera {
+	float origin[3];
+	float fwd[3], right[3], up[3];
+	float half_w, half_h;
+	float t_min, t_max;     /* Ray() defaults: 0.001f, FLT_MAX (ray.h:59) */
+} mrt_camera;
+
+/* RayStats, src/core/stats.h:20-55, plus device timing of the last cast. */
+typedef struct mrt_stats {
+	uint64_t rays_cast;
+	uint64_t tri_tests;          /* filled only when options.count_visits != 0 */
+	uint64_t bvh_nodes_visited;  /* idem: wide-node (internal) visits          */
+	uint64_t hits;               /* idem                                        */
+	float last_trace_ms;         /* hipEvent time of the trace kernel(s)        */
+	float last_sort_ms;          /* key+sort+gather kernels (0 if coherent)     */
+	float last_h2d_ms, last_d2h_ms;
+	uint32_t last_kernel_launches;
+	uint32_t max_stack_depth;    /* count_visits only                           */
+} mrt_stats;
+
+/* mode: RayQuery::Mode, src/api/ray_query.h:54-57 / RAY_MODE spec constant,
+ * bvh_traverse.comp.glsl:78 */
+enum { MRT_MODE_NEAREST = 0, MRT_MODE_ANY_HIT = 1 };
+
+/* flags for mrt_cast / mrt_submit */
+enum {
+	MRT_FLAG_COHERENT       = 1u << 0, /* RayQuery::coherent: skip the Morton sort (ray_dispatcher.h:135) */
+	MRT_FLAG_RAYS_ON_DEVICE = 1u << 1, /* `rays` is a device pointer (HBM-resident input)  */
+	MRT_FLAG_HITS_ON_DEVICE = 1u << 2, /* `hits` is a device pointer                      */
+	MRT_FLAG_HOST_LAYOUT    = 1u << 3, /* rays are mrt_host_ray60, hits are mrt_host_hit44 (conversion of
+	                                      gpu_ray_caster.cpp:639-650,442-456 runs on the device)          */
+	MRT_FLAG_BOOL_OUT       = 1u << 4, /* any-hit only: `hits` is uint8_t[count] (cast_rays_any_hit)     */
+	MRT_FLAG_FORCE_SORT     = 1u << 5  /* sort even if count < 256 (tests)                               */
+};
+
+/* kernel variants (options.kernel); 0 picks the default for the batch */
+enum {
+	MRT_KERNEL_AUTO = 0,
+	MRT_KERNEL_LANE = 1,    /* one lane = one ray, per-lane LDS stack, while-while loop         */
+	MRT_KERNEL_PACKET = 2   /* one wave = one 64-ray packet, per-wave LDS stack, scalar fetches */
+};
+
+typedef struct mrt_options {
+	uint32_t struct_size;     /* = sizeof(mrt_options) */
+	uint32_t kernel;          /* MRT_KERNEL_*                                        */
+	uint32_t count_visits;    /* 1: counting kernel variant fills mrt_stats counters  */
+	uint32_t sort_threshold;  /* MIN_BATCH_FOR_SORTING, default 256 (ray_dispatcher.h:427) */
+	uint32_t grid_tile;       /* 0: default 8x8 lane tiling for grid casts; 1: row-major */
+	uint32_t reserved[11];
+} mrt_options;
+
+typedef struct mrt_ctx mrt_ctx;
+
+/* ---- lifecycle: GPURayCaster::initialize / cleanup (gpu_ray_caster.cpp:72-183,700+) */
+int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out);
+void mrt_destroy(mrt_ctx *ctx);
+const char *mrt_last_error(const mrt_ctx *ctx);
+const char *mrt_status_string(int status);
+uint32_t mrt_version(void);
+/* Launch on this HIP stream (hipStream_t as void*; 0 = the context's own stream). */
+int mrt_set_stream(mrt_ctx *ctx, void *hip_stream);
+int mrt_synchronize(mrt_ctx *ctx);
+
+/* ---- host-side scene preparation (replaces RayScene::build + the conversion
+ *      half of upload_scene; no device needed) --------------------------------- */
+
+/* Triangle ctor, src/core/triangle.h:41-51: edge1, edge2, normal. */
+int mrt_make_triangles(const float *verts9, const uint32_t *ids, const uint32_t *layers,
+		uint32_t n_tris, mrt_tri64 *out);
+int mrt_pack_host_triangles(const mrt_host_tri80 *tris, uint32_t n_tris, mrt_tri64 *out);
+
+/* 8-bin SAH BVH2 over triangle AABBs with TinyBVH's node/primIdx conventions
+ * (replaces tinybvh::BVH::Build, tiny_bvh.h:2124-2136,2261-2466, called from
+ * src/accel/ray_scene.h:62-86).  verts: 3*n_tris vertices, 16-byte stride
+ * (bvhvec4).  nodes must hold 2*n_tris entries, prim_idx n_tris. */
+int mrt_bvh2_build(const float *verts4, uint32_t n_tris, mrt_bvh_node32 *nodes,
+		uint32_t *prim_idx, uint32_t *used_nodes, uint32_t n_threads);
+
+/* ---- scene upload: GPURayCaster::upload_scene (gpu_ray_caster.cpp:193-341) ---
+ * tris are in original order (tris[i] is the triangle with prim index i in
+ * prim_idx[]); the leaf -> prim_idx -> triangle indirection is resolved here
+ * (reference defect: SURVEY.md section 0, item 1) and arrays are sized by
+ * used_nodes (item 2).  Drains a pending async dispatch first (cpp:198-202). */
+int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
+		const mrt_bvh_node32 *nodes, uint32_t used_nodes, const uint32_t *prim_idx);
+int mrt_is_available(const mrt_ctx *ctx);      /* initialized && scene uploaded */
+int mrt_scene_info(const mrt_ctx *ctx, uint32_t *n_tris, uint32_t *n_wide_nodes, uint32_t *bvh_depth);
+
+/* ---- casting: GPURayCaster::cast_rays / cast_rays_any_hit (cpp:417-488) and
+ *      RayDispatcher's sort policy (ray_dispatcher.h:135-148).  Blocking. ------- */
+int mrt_cast(mrt_ctx *ctx, const void *rays, void *hits, uint64_t count,
+		uint32_t query_mask, int mode, uint32_t flags);
+
+/* ---- async: submit_async* / collect_* (cpp:536-623); one pending dispatch --- */
+int mrt_submit(mrt_ctx *ctx, const void *rays, uint64_t count,
+		uint32_t query_mask, int mode, uint32_t flags);
+int mrt_collect(mrt_ctx *ctx, void *hits, uint64_t count);
+int mrt_has_pending(const mrt_ctx *ctx);
+
+/* ---- primary-ray grids on the device (raytracer_debug.cpp:572-596) ---------- */
+int mrt_camera_look(mrt_camera *cam, const float origin[3], const float forward[3],
+		uint32_t grid_w, uint32_t grid_h, float fov_degrees);
+/* rows [y0,y1) of a grid_w x grid_h grid, row-major from row y0, into d_rays. */
+int mrt_generate_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t grid_h,
+		uint32_t y0, uint32_t y1, mrt_ray32 *d_rays);
+/* Fused: generate rows [y0,y1) and trace them; hits row-major from row y0
+ * (device pointer iff MRT_FLAG_HITS_ON_DEVICE). */
+int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t grid_h,
+		uint32_t y0, uint32_t y1, void *hits, uint32_t query_mask, int mode, uint32_t flags);
+/* Trace device-resident rays that the caller declares to be a row-major
+ * grid_w-wide grid (lets the kernel tile lanes 8x8 instead of 64x1). */
+int mrt_cast_tiled(mrt_ctx *ctx, const mrt_ray32 *d_rays, mrt_hit32 *d_hits,
+		uint32_t grid_w, uint32_t rows, uint32_t query_mask, int mode);
+
+/* ---- Morton keys (src/dispatch/ray_sort.h:41-76), exposed for parity tests ---- */
+int mrt_morton_keys(mrt_ctx *ctx, const mrt_ray32 *d_rays, uint64_t count, uint32_t *d_keys);
+
+/* ---- stats / device memory helpers ---------------------------------------- */
+int mrt_get_stats(mrt_ctx *ctx, mrt_stats *out);
+int mrt_device_alloc(mrt_ctx *ctx, size_t bytes, void **d_ptr);
+int mrt_device_free(mrt_ctx *ctx, void *d_ptr);
+int mrt_memcpy_h2d(mrt_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int mrt_memcpy_d2h(mrt_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRT_HIP_H_ */

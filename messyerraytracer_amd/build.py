@@ -1,0 +1,61 @@
+"""Builds libmrt_hip.so (the C-ABI library: HIP kernels for gfx950 + host-side
+scene preparation) in-tree with hipcc.  hipcc cross-compiles without a GPU."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libmrt_hip.so")
+HOST_TEST = os.path.join(HERE, "host_mirror_test")
+
+SOURCES = ["kernels.hip", "api.hip", "host/scene_prep.cpp", "host/bvh_builder.cpp"]
+HEADERS = ["mrt_internal.h", "../../include/mrt_hip.h", "host/gpu_ray_caster.hpp", "host/ray_dispatcher.hpp",
+           "host/host_types.hpp"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",
+         "-Wno-unused-result"]
+
+
+def _hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libmrt_hip.so cannot be built")
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build_lib(force: bool = False, verbose: bool = False) -> str:
+    srcs = [os.path.join(CSRC, s) for s in SOURCES]
+    deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    if force or _stale(LIB, deps):
+        cmd = [_hipcc()] + FLAGS + ["-shared"] + srcs + ["-o", LIB, "-pthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+        if verbose:
+            print(r.stderr)
+    return LIB
+
+
+def build_host_test(force: bool = False) -> str:
+    """C++ test driver for the GPURayCaster / RayDispatcher mirrors (links the C-ABI)."""
+    src = os.path.join(CSRC, "host", "host_mirror_test.cpp")
+    deps = [src, LIB] + [os.path.join(CSRC, h) for h in HEADERS]
+    if force or _stale(HOST_TEST, deps):
+        cmd = [_hipcc(), "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", src, "-o", HOST_TEST,
+               "-L" + HERE, "-lmrt_hip", "-Wl,-rpath," + HERE, "-pthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+        if r.returncode != 0:
+            raise RuntimeError("host test build failed:\n" + r.stdout + r.stderr)
+    return HOST_TEST
+
+
+if __name__ == "__main__":
+    print(build_lib(force=True, verbose=True))
+    print(build_host_test(force=True))

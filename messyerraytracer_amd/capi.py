@@ -1,0 +1,293 @@
+"""ctypes binding of the C-ABI in include/mrt_hip.h (libmrt_hip.so).
+
+This is plumbing for tests and bench.py; the product is the shared library.
+There is no fallback: if the library is missing or fails to load, importing
+callers get an ImportError / MrtError, never a CPU path.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import types as T
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libmrt_hip.so")
+
+MRT_OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SCENE, ERR_PENDING, ERR_NOT_PENDING, ERR_OOM, ERR_UNSUPPORTED, ERR_BAD_BVH = range(1, 10)
+MODE_NEAREST, MODE_ANY_HIT = 0, 1
+FLAG_COHERENT, FLAG_RAYS_ON_DEVICE, FLAG_HITS_ON_DEVICE, FLAG_HOST_LAYOUT, FLAG_BOOL_OUT, FLAG_FORCE_SORT = (1 << i for i in range(6))
+KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET = 0, 1, 2
+
+# every entry point include/mrt_hip.h declares (tests check they are all exported)
+SYMBOLS = [
+    "mrt_create", "mrt_destroy", "mrt_last_error", "mrt_status_string", "mrt_version", "mrt_set_stream",
+    "mrt_synchronize", "mrt_make_triangles", "mrt_pack_host_triangles", "mrt_bvh2_build", "mrt_upload_scene",
+    "mrt_is_available", "mrt_scene_info", "mrt_cast", "mrt_submit", "mrt_collect", "mrt_has_pending",
+    "mrt_camera_look", "mrt_generate_grid", "mrt_cast_grid", "mrt_cast_tiled", "mrt_morton_keys",
+    "mrt_get_stats", "mrt_device_alloc", "mrt_device_free", "mrt_memcpy_h2d", "mrt_memcpy_d2h",
+]
+
+
+class MrtError(RuntimeError):
+    def __init__(self, status, msg):
+        super().__init__(f"mrt status {status}: {msg}")
+        self.status = status
+
+
+class Options(C.Structure):
+    _fields_ = [("struct_size", C.c_uint32), ("kernel", C.c_uint32), ("count_visits", C.c_uint32),
+                ("sort_threshold", C.c_uint32), ("grid_tile", C.c_uint32), ("reserved", C.c_uint32 * 11)]
+
+
+class Camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("fwd", C.c_float * 3), ("right", C.c_float * 3), ("up", C.c_float * 3),
+                ("half_w", C.c_float), ("half_h", C.c_float), ("t_min", C.c_float), ("t_max", C.c_float)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("rays_cast", C.c_uint64), ("tri_tests", C.c_uint64), ("bvh_nodes_visited", C.c_uint64),
+                ("hits", C.c_uint64), ("last_trace_ms", C.c_float), ("last_sort_ms", C.c_float),
+                ("last_h2d_ms", C.c_float), ("last_d2h_ms", C.c_float), ("last_kernel_launches", C.c_uint32),
+                ("max_stack_depth", C.c_uint32)]
+
+
+_lib = None
+
+
+def load():
+    """Loads libmrt_hip.so; raises ImportError if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(the HIP extension is the product; there is no CPU fallback)")
+    L = C.CDLL(LIB_PATH)
+    L.mrt_last_error.restype = C.c_char_p
+    L.mrt_status_string.restype = C.c_char_p
+    L.mrt_version.restype = C.c_uint32
+    L.mrt_create.argtypes = [C.c_int, C.POINTER(Options), C.POINTER(C.c_void_p)]
+    L.mrt_destroy.argtypes = [C.c_void_p]
+    L.mrt_destroy.restype = None
+    L.mrt_last_error.argtypes = [C.c_void_p]
+    L.mrt_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.mrt_synchronize.argtypes = [C.c_void_p]
+    L.mrt_make_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.mrt_pack_host_triangles.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.mrt_bvh2_build.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+    L.mrt_upload_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.mrt_is_available.argtypes = [C.c_void_p]
+    L.mrt_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.mrt_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32]
+    L.mrt_submit.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32]
+    L.mrt_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+    L.mrt_has_pending.argtypes = [C.c_void_p]
+    L.mrt_camera_look.argtypes = [C.POINTER(Camera), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_float]
+    L.mrt_generate_grid.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.mrt_cast_grid.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
+    L.mrt_cast_tiled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.mrt_morton_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
+    L.mrt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.mrt_device_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
+    L.mrt_device_free.argtypes = [C.c_void_p, C.c_void_p]
+    L.mrt_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mrt_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    _lib = L
+    return L
+
+
+def _np(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _ptr(x):
+    """numpy array -> host pointer; int -> raw (device) pointer; torch tensor -> data_ptr()."""
+    if isinstance(x, np.ndarray):
+        return _np(x)
+    if isinstance(x, int):
+        return C.c_void_p(x)
+    if hasattr(x, "data_ptr"):
+        return C.c_void_p(x.data_ptr())
+    raise TypeError(type(x))
+
+
+# ---- host-side helpers (no device needed) ---------------------------------------
+def make_triangles(verts9, ids=None, layers=None) -> np.ndarray:
+    v = np.ascontiguousarray(verts9, dtype=np.float32).reshape(-1, 9)
+    out = np.zeros(v.shape[0], dtype=T.TRI64)
+    ids_a = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
+    lay_a = None if layers is None else np.ascontiguousarray(layers, dtype=np.uint32)
+    rc = load().mrt_make_triangles(_np(v), None if ids_a is None else _np(ids_a), None if lay_a is None else _np(lay_a),
+                                   v.shape[0], _np(out))
+    if rc:
+        raise MrtError(rc, "mrt_make_triangles")
+    return out
+
+
+def bvh2_build(verts4: np.ndarray, n_threads: int = 0):
+    v4 = np.ascontiguousarray(verts4, dtype=np.float32)
+    n = v4.shape[0] // 3
+    nodes = np.zeros(2 * n + 2, dtype=T.NODE32)
+    prim_idx = np.zeros(n, dtype=np.uint32)
+    used = C.c_uint32(0)
+    rc = load().mrt_bvh2_build(_np(v4), n, _np(nodes), _np(prim_idx), C.byref(used), n_threads)
+    if rc:
+        raise MrtError(rc, "mrt_bvh2_build")
+    return nodes[:used.value].copy(), prim_idx, used.value
+
+
+def camera_look(origin, forward, grid_w, grid_h, fov_degrees) -> Camera:
+    cam = Camera()
+    o = (C.c_float * 3)(*origin)
+    f = (C.c_float * 3)(*forward)
+    rc = load().mrt_camera_look(C.byref(cam), o, f, grid_w, grid_h, fov_degrees)
+    if rc:
+        raise MrtError(rc, "mrt_camera_look")
+    return cam
+
+
+class Context:
+    """mrt_ctx wrapper: one per GPU, externally serialised (SURVEY 8(b) threading)."""
+
+    def __init__(self, device: int = 0, kernel: int = KERNEL_AUTO, count_visits: bool = False,
+                 sort_threshold: int = 0, grid_tile: int = 0):
+        self.L = load()
+        opts = Options()
+        opts.struct_size = C.sizeof(Options)
+        opts.kernel = kernel
+        opts.count_visits = 1 if count_visits else 0
+        opts.sort_threshold = sort_threshold
+        opts.grid_tile = grid_tile
+        self.h = C.c_void_p()
+        rc = self.L.mrt_create(device, C.byref(opts), C.byref(self.h))
+        if rc:
+            raise MrtError(rc, self.L.mrt_status_string(rc).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mrt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc:
+            raise MrtError(rc, self.L.mrt_last_error(self.h).decode() or self.L.mrt_status_string(rc).decode())
+
+    def set_stream(self, stream_ptr: int):
+        self._chk(self.L.mrt_set_stream(self.h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self._chk(self.L.mrt_synchronize(self.h))
+
+    def upload_scene(self, tris, nodes, prim_idx):
+        tris = np.ascontiguousarray(tris)
+        nodes = np.ascontiguousarray(nodes)
+        prim_idx = np.ascontiguousarray(prim_idx, dtype=np.uint32)
+        assert tris.dtype == T.TRI64 and nodes.dtype == T.NODE32
+        self._chk(self.L.mrt_upload_scene(self.h, _np(tris), tris.shape[0], _np(nodes), nodes.shape[0], _np(prim_idx)))
+
+    def is_available(self) -> bool:
+        return bool(self.L.mrt_is_available(self.h))
+
+    def scene_info(self):
+        a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        self._chk(self.L.mrt_scene_info(self.h, C.byref(a), C.byref(b), C.byref(c)))
+        return dict(n_tris=a.value, n_wide_nodes=b.value, stack_need=c.value)
+
+    def cast(self, rays, hits=None, count=None, query_mask=0xFFFFFFFF, mode=MODE_NEAREST, flags=0):
+        """rays / hits: numpy arrays (host) or ints / torch tensors (device, with the matching flag)."""
+        if count is None:
+            count = rays.shape[0]
+        if hits is None:
+            if flags & FLAG_BOOL_OUT:
+                hits = np.zeros(count, dtype=np.uint8)
+            elif flags & FLAG_HOST_LAYOUT:
+                hits = np.zeros(count, dtype=T.HOST_HIT44)
+            else:
+                hits = np.zeros(count, dtype=T.HIT32)
+        if isinstance(rays, np.ndarray):
+            rays = np.ascontiguousarray(rays)
+        self._chk(self.L.mrt_cast(self.h, _ptr(rays), _ptr(hits), count, query_mask, mode, flags))
+        return hits
+
+    def submit(self, rays, count=None, query_mask=0xFFFFFFFF, mode=MODE_NEAREST, flags=0):
+        if count is None:
+            count = rays.shape[0]
+        self._keep = rays  # caller must keep rays alive until collect (gpu_ray_caster.cpp:542)
+        self._chk(self.L.mrt_submit(self.h, _ptr(rays), count, query_mask, mode, flags))
+        self._pending = (count, mode, flags)
+
+    def collect(self, hits=None, count=None):
+        pc, mode, flags = getattr(self, "_pending", (0, 0, 0))
+        if count is None:
+            count = pc
+        if hits is None:
+            if flags & FLAG_BOOL_OUT:
+                hits = np.zeros(count, dtype=np.uint8)
+            elif flags & FLAG_HOST_LAYOUT:
+                hits = np.zeros(count, dtype=T.HOST_HIT44)
+            else:
+                hits = np.zeros(count, dtype=T.HIT32)
+        self._chk(self.L.mrt_collect(self.h, _ptr(hits), count))
+        return hits
+
+    def has_pending(self) -> bool:
+        return bool(self.L.mrt_has_pending(self.h))
+
+    def generate_grid(self, cam, grid_w, grid_h, y0, y1, d_rays):
+        self._chk(self.L.mrt_generate_grid(self.h, C.byref(cam), grid_w, grid_h, y0, y1, _ptr(d_rays)))
+
+    def cast_grid(self, cam, grid_w, grid_h, y0=0, y1=None, hits=None, query_mask=0xFFFFFFFF, mode=MODE_NEAREST, flags=0):
+        y1 = grid_h if y1 is None else y1
+        n = grid_w * (y1 - y0)
+        if hits is None:
+            hits = np.zeros(n, dtype=np.uint8 if (flags & FLAG_BOOL_OUT) else T.HIT32)
+        self._chk(self.L.mrt_cast_grid(self.h, C.byref(cam), grid_w, grid_h, y0, y1, _ptr(hits), query_mask, mode, flags))
+        return hits
+
+    def cast_tiled(self, d_rays, d_hits, grid_w, rows, query_mask=0xFFFFFFFF, mode=MODE_NEAREST):
+        self._chk(self.L.mrt_cast_tiled(self.h, _ptr(d_rays), _ptr(d_hits), grid_w, rows, query_mask, mode))
+
+    def morton_keys(self, d_rays, count, d_keys):
+        self._chk(self.L.mrt_morton_keys(self.h, _ptr(d_rays), count, _ptr(d_keys)))
+
+    def stats(self) -> dict:
+        s = Stats()
+        self._chk(self.L.mrt_get_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def device_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._chk(self.L.mrt_device_alloc(self.h, nbytes, C.byref(p)))
+        return p.value
+
+    def device_free(self, ptr: int):
+        self._chk(self.L.mrt_device_free(self.h, C.c_void_p(ptr)))
+
+    def h2d(self, d_ptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._chk(self.L.mrt_memcpy_h2d(self.h, C.c_void_p(d_ptr), _np(arr), arr.nbytes))
+
+    def d2h(self, arr: np.ndarray, d_ptr: int):
+        self._chk(self.L.mrt_memcpy_d2h(self.h, _np(arr), C.c_void_p(d_ptr), arr.nbytes))
+
+
+class Scene:
+    """Host-side scene: Triangle ctor -> 8-bin SAH BVH2, i.e. what RayScene::build
+    hands to upload_scene (src/accel/ray_scene.h:62-86)."""
+
+    def __init__(self, verts9, ids=None, layers=None, n_threads: int = 0):
+        self.tris = make_triangles(verts9, ids, layers)
+        self.verts4 = T.verts4_from_verts9(verts9)
+        self.nodes, self.prim_idx, self.used_nodes = bvh2_build(self.verts4, n_threads)
+
+    def upload(self, ctx: Context):
+        ctx.upload_scene(self.tris, self.nodes, self.prim_idx)

@@ -1,0 +1,496 @@
+// api.hip — the C-ABI of include/mrt_hip.h: context, scene upload, casts.
+//
+// Mirrors GPURayCaster (src/gpu/gpu_ray_caster.{h,cpp}) and the GPU half of
+// RayDispatcher's policy (src/dispatch/ray_dispatcher.h:124-356): grow-only
+// per-dispatch buffers (cpp:776-817), one pending async dispatch (cpp:538),
+// upload drains a pending dispatch (cpp:198-202), Morton sort for incoherent
+// batches of >= 256 rays (ray_dispatcher.h:135,427) — the sort, the gather and
+// the unshuffle all run on the device (radix sort + permuted load/store inside
+// the trace kernel) instead of std::sort + three host copies.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string.h>
+#include <new>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include "mrt_internal.h"
+
+namespace mrt {
+hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream);
+hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t stream);
+hipError_t launch_morton_keys(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t *keys, uint32_t *index, hipStream_t stream);
+}
+
+struct DevBuf {
+	void *ptr = nullptr;
+	size_t cap = 0;
+};
+
+struct mrt_ctx {
+	int device = 0;
+	mrt_options opts{};
+	hipStream_t own_stream = nullptr;
+	hipStream_t stream = nullptr;
+	hipEvent_t ev[6] = {};
+	char err[512] = {0};
+	// scene
+	mrt::DevNode *d_nodes = nullptr; mrt::TriHot *d_hot = nullptr; mrt::TriCold *d_cold = nullptr;
+	uint32_t n_nodes = 0, n_tris = 0, depth = 0, stack_depth = 0;
+	bool scene = false;
+	// per-dispatch buffers (grow only, x1.5: gpu_ray_caster.cpp:776-817)
+	DevBuf rays, hits, keys_in, keys_out, idx_in, idx_out, sort_tmp;
+	unsigned long long *d_counters = nullptr;
+	// async state
+	bool pending = false;
+	uint64_t pending_count = 0; uint32_t pending_flags = 0; int pending_mode = 0;
+	const void *pending_dev_hits = nullptr;
+	mrt_stats stats{};
+};
+
+namespace {
+
+#define HIP_TRY(ctx, call)                                                                          \
+	do {                                                                                            \
+		hipError_t e_ = (call);                                                                     \
+		if (e_ != hipSuccess) {                                                                     \
+			std::snprintf((ctx)->err, sizeof((ctx)->err), "%s failed: %s (%s:%d)", #call,           \
+					hipGetErrorString(e_), __FILE__, __LINE__);                                      \
+			return MRT_ERR_HIP;                                                                     \
+		}                                                                                           \
+	} while (0)
+
+int fail(mrt_ctx *ctx, int code, const char *msg)
+{
+	if (ctx) std::snprintf(ctx->err, sizeof(ctx->err), "%s", msg);
+	return code;
+}
+
+int ensure(mrt_ctx *ctx, DevBuf &b, size_t bytes)
+{
+	if (b.cap >= bytes) return MRT_OK;
+	size_t want = bytes + bytes / 2; // grow x1.5
+	if (b.ptr) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); HIP_TRY(ctx, hipFree(b.ptr)); b.ptr = nullptr; b.cap = 0; }
+	hipError_t e = hipMalloc(&b.ptr, want);
+	if (e != hipSuccess) { want = bytes; e = hipMalloc(&b.ptr, want); }
+	if (e != hipSuccess) { b.ptr = nullptr; return fail(ctx, MRT_ERR_OOM, "device allocation failed"); }
+	b.cap = want;
+	return MRT_OK;
+}
+
+void release(DevBuf &b) { if (b.ptr) (void)hipFree(b.ptr); b.ptr = nullptr; b.cap = 0; }
+
+void free_scene(mrt_ctx *ctx)
+{
+	if (ctx->d_nodes) (void)hipFree(ctx->d_nodes);
+	if (ctx->d_hot) (void)hipFree(ctx->d_hot);
+	if (ctx->d_cold) (void)hipFree(ctx->d_cold);
+	ctx->d_nodes = nullptr; ctx->d_hot = nullptr; ctx->d_cold = nullptr;
+	ctx->scene = false; ctx->n_nodes = ctx->n_tris = 0;
+}
+
+size_t ray_stride(uint32_t flags) { return (flags & MRT_FLAG_HOST_LAYOUT) ? sizeof(mrt_host_ray60) : sizeof(mrt_ray32); }
+size_t hit_stride(uint32_t flags, int mode)
+{
+	if ((flags & MRT_FLAG_BOOL_OUT) && mode == MRT_MODE_ANY_HIT) return 1;
+	return (flags & MRT_FLAG_HOST_LAYOUT) ? sizeof(mrt_host_hit44) : sizeof(mrt_hit32);
+}
+
+void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
+{
+	std::memset(&p, 0, sizeof(p));
+	p.nodes = ctx->d_nodes; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold;
+	p.stack_depth = ctx->stack_depth;
+	p.counters = ctx->d_counters;
+	p.xcd_swizzle = 1;
+}
+
+int drain_pending(mrt_ctx *ctx)
+{
+	if (ctx->pending) { HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); ctx->pending = false; }
+	return MRT_OK;
+}
+
+// Sorts ray indices by direction Morton key on the device; returns the permutation in idx_out.
+int device_sort(mrt_ctx *ctx, const void *d_rays, uint32_t in_fmt, uint64_t count, const uint32_t **perm)
+{
+	if (count > 0xFFFFFFFFull) return fail(ctx, MRT_ERR_UNSUPPORTED, "sorted batches are limited to 2^32-1 rays");
+	int rc;
+	if ((rc = ensure(ctx, ctx->keys_in, count * 4)) || (rc = ensure(ctx, ctx->keys_out, count * 4)) ||
+			(rc = ensure(ctx, ctx->idx_in, count * 4)) || (rc = ensure(ctx, ctx->idx_out, count * 4))) return rc;
+	uint32_t *ki = (uint32_t *)ctx->keys_in.ptr, *ko = (uint32_t *)ctx->keys_out.ptr;
+	uint32_t *ii = (uint32_t *)ctx->idx_in.ptr, *io = (uint32_t *)ctx->idx_out.ptr;
+	HIP_TRY(ctx, mrt::launch_morton_keys(d_rays, in_fmt, count, ki, ii, ctx->stream));
+	size_t tmp_bytes = 0;
+	HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, ki, ko, ii, io, (size_t)count, 0, 30, ctx->stream));
+	if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes ? tmp_bytes : 16))) return rc;
+	HIP_TRY(ctx, rocprim::radix_sort_pairs(ctx->sort_tmp.ptr, tmp_bytes, ki, ko, ii, io, (size_t)count, 0, 30, ctx->stream));
+	*perm = io;
+	return MRT_OK;
+}
+
+// Enqueue H2D (if needed) + optional sort + trace.  On return the kernels are queued on ctx->stream.
+int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_t count, uint32_t query_mask,
+		int mode, uint32_t flags, void **d_hits_out)
+{
+	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded (is_available() == false)");
+	if (mode != MRT_MODE_NEAREST && mode != MRT_MODE_ANY_HIT) return fail(ctx, MRT_ERR_INVALID, "bad mode");
+	if ((flags & MRT_FLAG_BOOL_OUT) && mode != MRT_MODE_ANY_HIT) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT needs any-hit mode");
+	const size_t rs = ray_stride(flags), hs = hit_stride(flags, mode);
+	int rc;
+	const void *d_rays = rays;
+	ctx->stats.last_h2d_ms = ctx->stats.last_d2h_ms = ctx->stats.last_sort_ms = 0.0f;
+	if (!(flags & MRT_FLAG_RAYS_ON_DEVICE)) {
+		if ((rc = ensure(ctx, ctx->rays, count * rs))) return rc;
+		HIP_TRY(ctx, hipEventRecord(ctx->ev[0], ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(ctx->rays.ptr, rays, count * rs, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipEventRecord(ctx->ev[1], ctx->stream));
+		d_rays = ctx->rays.ptr;
+	}
+	void *d_hits = hits_dev_or_null;
+	if (!d_hits) {
+		if ((rc = ensure(ctx, ctx->hits, count * hs))) return rc;
+		d_hits = ctx->hits.ptr;
+	}
+	mrt::TraceParams p;
+	base_params(ctx, p);
+	p.rays = d_rays; p.hits = d_hits; p.count = count; p.query_mask = query_mask;
+	p.in_fmt = (flags & MRT_FLAG_HOST_LAYOUT) ? mrt::IN_HOST60 : mrt::IN_RAY32;
+	p.out_fmt = hs == 1 ? mrt::OUT_BOOL8 : ((flags & MRT_FLAG_HOST_LAYOUT) ? mrt::OUT_HOST44 : mrt::OUT_HIT32);
+	p.lane_map = mrt::MAP_LINEAR;
+	const uint32_t thr = ctx->opts.sort_threshold ? ctx->opts.sort_threshold : 256u; // MIN_BATCH_FOR_SORTING
+	const bool sort = !(flags & MRT_FLAG_COHERENT) && (count >= thr || (flags & MRT_FLAG_FORCE_SORT));
+	HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+	if (sort) {
+		const uint32_t *perm = nullptr;
+		if ((rc = device_sort(ctx, d_rays, p.in_fmt, count, &perm))) return rc;
+		p.perm = perm;
+	}
+	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
+	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+	ctx->stats.last_kernel_launches = sort ? 3 : 1;
+	ctx->stats.rays_cast += count;
+	*d_hits_out = d_hits;
+	return MRT_OK;
+}
+
+int finish_timing(mrt_ctx *ctx, bool h2d, bool sorted, bool d2h)
+{
+	float ms = 0.0f;
+	if (h2d) { HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1])); ctx->stats.last_h2d_ms = ms; }
+	if (sorted) { HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.last_sort_ms = ms; }
+	HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); ctx->stats.last_trace_ms = ms;
+	if (d2h) { HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->stats.last_d2h_ms = ms; }
+	if (ctx->opts.count_visits) {
+		unsigned long long c[8];
+		HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+		ctx->stats.tri_tests += c[1]; ctx->stats.bvh_nodes_visited += c[2]; ctx->stats.hits += c[3];
+		if ((uint32_t)c[4] > ctx->stats.max_stack_depth) ctx->stats.max_stack_depth = (uint32_t)c[4];
+	}
+	return MRT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t mrt_version(void) { return (MRT_VERSION_MAJOR << 16) | MRT_VERSION_MINOR; }
+
+const char *mrt_status_string(int s)
+{
+	switch (s) {
+		case MRT_OK: return "ok";
+		case MRT_ERR_INVALID: return "invalid argument";
+		case MRT_ERR_NO_DEVICE: return "no such HIP device";
+		case MRT_ERR_HIP: return "HIP runtime error";
+		case MRT_ERR_NO_SCENE: return "no scene uploaded";
+		case MRT_ERR_PENDING: return "an async dispatch is already pending";
+		case MRT_ERR_NOT_PENDING: return "no async dispatch pending";
+		case MRT_ERR_OOM: return "out of memory";
+		case MRT_ERR_UNSUPPORTED: return "unsupported";
+		case MRT_ERR_BAD_BVH: return "BVH failed validation";
+		default: return "unknown status";
+	}
+}
+
+const char *mrt_last_error(const mrt_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
+{
+	if (!out) return MRT_ERR_INVALID;
+	*out = nullptr;
+	if (opts && opts->struct_size != sizeof(mrt_options)) return MRT_ERR_INVALID;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || device_ordinal < 0 || device_ordinal >= n) return MRT_ERR_NO_DEVICE;
+	mrt_ctx *ctx = new (std::nothrow) mrt_ctx();
+	if (!ctx) return MRT_ERR_OOM;
+	ctx->device = device_ordinal;
+	if (opts) ctx->opts = *opts;
+	ctx->opts.struct_size = sizeof(mrt_options);
+	auto bail = [&](int code) { mrt_destroy(ctx); return code; };
+	if (hipSetDevice(device_ordinal) != hipSuccess) return bail(MRT_ERR_NO_DEVICE);
+	if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(MRT_ERR_HIP);
+	ctx->stream = ctx->own_stream;
+	for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) return bail(MRT_ERR_HIP);
+	if (hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_OOM);
+	*out = ctx;
+	return MRT_OK;
+}
+
+void mrt_destroy(mrt_ctx *ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+	free_scene(ctx);
+	release(ctx->rays); release(ctx->hits); release(ctx->keys_in); release(ctx->keys_out);
+	release(ctx->idx_in); release(ctx->idx_out); release(ctx->sort_tmp);
+	if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+	delete ctx;
+}
+
+int mrt_set_stream(mrt_ctx *ctx, void *hip_stream)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	if (ctx->pending) return fail(ctx, MRT_ERR_PENDING, "cannot switch streams with a dispatch pending");
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+	return MRT_OK;
+}
+
+int mrt_synchronize(mrt_ctx *ctx)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return MRT_OK;
+}
+
+int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
+		const mrt_bvh_node32 *nodes, uint32_t used_nodes, const uint32_t *prim_idx)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = drain_pending(ctx); // gpu_ray_caster.cpp:198-202
+	if (rc) return rc;
+	mrt::DeviceSceneHost h;
+	rc = mrt::prepare_scene(tris, n_tris, nodes, used_nodes, prim_idx, &h, ctx->err, sizeof(ctx->err));
+	if (rc) return rc;
+	auto cleanup = [&] { std::free(h.nodes); std::free(h.hot); std::free(h.cold); };
+	if (h.depth > 64) { cleanup(); return fail(ctx, MRT_ERR_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack"); }
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	free_scene(ctx);
+	hipError_t e;
+	if ((e = hipMalloc(&ctx->d_nodes, (size_t)h.n_nodes * sizeof(mrt::DevNode))) != hipSuccess ||
+			(e = hipMalloc(&ctx->d_hot, (size_t)h.n_tris * sizeof(mrt::TriHot))) != hipSuccess ||
+			(e = hipMalloc(&ctx->d_cold, (size_t)h.n_tris * sizeof(mrt::TriCold))) != hipSuccess) {
+		cleanup(); free_scene(ctx);
+		return fail(ctx, MRT_ERR_OOM, "scene does not fit in device memory");
+	}
+	e = hipMemcpy(ctx->d_nodes, h.nodes, (size_t)h.n_nodes * sizeof(mrt::DevNode), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(ctx->d_hot, h.hot, (size_t)h.n_tris * sizeof(mrt::TriHot), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(ctx->d_cold, h.cold, (size_t)h.n_tris * sizeof(mrt::TriCold), hipMemcpyHostToDevice);
+	cleanup();
+	if (e != hipSuccess) { free_scene(ctx); std::snprintf(ctx->err, sizeof(ctx->err), "scene upload failed: %s", hipGetErrorString(e)); return MRT_ERR_HIP; }
+	ctx->n_nodes = h.n_nodes; ctx->n_tris = h.n_tris; ctx->depth = h.depth;
+	// LDS stack entries per lane: what this BVH can need, rounded up to 8, at most 64.
+	ctx->stack_depth = ((h.depth + 7u) / 8u) * 8u;
+	if (ctx->stack_depth < 8) ctx->stack_depth = 8;
+	ctx->scene = true;
+	return MRT_OK;
+}
+
+int mrt_is_available(const mrt_ctx *ctx) { return ctx && ctx->scene ? 1 : 0; }
+
+int mrt_scene_info(const mrt_ctx *ctx, uint32_t *n_tris, uint32_t *n_wide_nodes, uint32_t *bvh_depth)
+{
+	if (!ctx || !ctx->scene) return MRT_ERR_NO_SCENE;
+	if (n_tris) *n_tris = ctx->n_tris;
+	if (n_wide_nodes) *n_wide_nodes = ctx->n_nodes;
+	if (bvh_depth) *bvh_depth = ctx->depth;
+	return MRT_OK;
+}
+
+int mrt_cast(mrt_ctx *ctx, const void *rays, void *hits, uint64_t count, uint32_t query_mask, int mode, uint32_t flags)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	if (count == 0) return ctx->scene ? MRT_OK : fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded"); // cpp:419: silent no-op
+	if (!rays || !hits) return fail(ctx, MRT_ERR_INVALID, "null rays / hits");
+	if (ctx->pending) return fail(ctx, MRT_ERR_PENDING, "collect the pending dispatch first");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	void *d_hits = nullptr;
+	const bool hits_dev = (flags & MRT_FLAG_HITS_ON_DEVICE) != 0;
+	int rc = enqueue_cast(ctx, rays, hits_dev ? hits : nullptr, count, query_mask, mode, flags, &d_hits);
+	if (rc) return rc;
+	if (!hits_dev) {
+		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, count * hit_stride(flags, mode), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+	}
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return finish_timing(ctx, !(flags & MRT_FLAG_RAYS_ON_DEVICE), ctx->stats.last_kernel_launches == 3, !hits_dev);
+}
+
+int mrt_submit(mrt_ctx *ctx, const void *rays, uint64_t count, uint32_t query_mask, int mode, uint32_t flags)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	if (ctx->pending) return fail(ctx, MRT_ERR_PENDING, "submit while a dispatch is pending (gpu_ray_caster.cpp:538)");
+	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded");
+	if (count == 0) return MRT_OK;
+	if (!rays) return fail(ctx, MRT_ERR_INVALID, "null rays");
+	if (flags & MRT_FLAG_HITS_ON_DEVICE) return fail(ctx, MRT_ERR_INVALID, "submit keeps results in the context; use mrt_cast for device outputs");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	void *d_hits = nullptr;
+	int rc = enqueue_cast(ctx, rays, nullptr, count, query_mask, mode, flags, &d_hits);
+	if (rc) return rc;
+	ctx->pending = true; ctx->pending_count = count; ctx->pending_flags = flags; ctx->pending_mode = mode;
+	ctx->pending_dev_hits = d_hits;
+	return MRT_OK;
+}
+
+int mrt_collect(mrt_ctx *ctx, void *hits, uint64_t count)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	if (!ctx->pending) return fail(ctx, MRT_ERR_NOT_PENDING, "collect without a pending dispatch");
+	if (!hits) return fail(ctx, MRT_ERR_INVALID, "null hits");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	const uint64_t n = count < ctx->pending_count ? count : ctx->pending_count; // cpp:573
+	HIP_TRY(ctx, hipMemcpyAsync(hits, ctx->pending_dev_hits, n * hit_stride(ctx->pending_flags, ctx->pending_mode),
+			hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->pending = false;
+	return finish_timing(ctx, !(ctx->pending_flags & MRT_FLAG_RAYS_ON_DEVICE), ctx->stats.last_kernel_launches == 3, true);
+}
+
+int mrt_has_pending(const mrt_ctx *ctx) { return ctx && ctx->pending ? 1 : 0; }
+
+static int grid_params(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t grid_h, uint32_t y0, uint32_t y1, mrt::TraceParams &p)
+{
+	if (!cam || grid_w == 0 || grid_h == 0 || y0 > y1 || y1 > grid_h) return fail(ctx, MRT_ERR_INVALID, "bad grid");
+	base_params(ctx, p);
+	p.cam = *cam; p.grid_w = grid_w; p.grid_h = grid_h; p.y0 = y0; p.rows = y1 - y0;
+	p.tiles_x = (grid_w + 7u) / 8u;
+	p.count = (uint64_t)grid_w * (y1 - y0);
+	p.in_fmt = mrt::IN_GRID;
+	return MRT_OK;
+}
+
+int mrt_generate_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t grid_h,
+		uint32_t y0, uint32_t y1, mrt_ray32 *d_rays)
+{
+	if (!ctx || !d_rays) return MRT_ERR_INVALID;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	mrt::TraceParams p;
+	int rc = grid_params(ctx, cam, grid_w, grid_h, y0, y1, p);
+	if (rc) return rc;
+	HIP_TRY(ctx, mrt::launch_grid_rays(p, d_rays, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return MRT_OK;
+}
+
+int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t grid_h,
+		uint32_t y0, uint32_t y1, void *hits, uint32_t query_mask, int mode, uint32_t flags)
+{
+	if (!ctx || !hits) return MRT_ERR_INVALID;
+	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded");
+	if (ctx->pending) return fail(ctx, MRT_ERR_PENDING, "collect the pending dispatch first");
+	if (flags & MRT_FLAG_HOST_LAYOUT) return fail(ctx, MRT_ERR_UNSUPPORTED, "grid casts write packed hits");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	mrt::TraceParams p;
+	int rc = grid_params(ctx, cam, grid_w, grid_h, y0, y1, p);
+	if (rc) return rc;
+	if (p.count == 0) return MRT_OK;
+	const size_t hs = hit_stride(flags, mode);
+	const bool hits_dev = (flags & MRT_FLAG_HITS_ON_DEVICE) != 0;
+	void *d_hits = hits;
+	if (!hits_dev) { if ((rc = ensure(ctx, ctx->hits, p.count * hs))) return rc; d_hits = ctx->hits.ptr; }
+	p.hits = d_hits; p.query_mask = query_mask;
+	p.out_fmt = hs == 1 ? mrt::OUT_BOOL8 : mrt::OUT_HIT32;
+	p.lane_map = ctx->opts.grid_tile == 1 ? mrt::MAP_LINEAR : mrt::MAP_TILE8X8;
+	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
+	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+	if (!hits_dev) {
+		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, p.count * hs, hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
+	}
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->stats.last_kernel_launches = 1; ctx->stats.rays_cast += p.count;
+	ctx->stats.last_h2d_ms = ctx->stats.last_sort_ms = ctx->stats.last_d2h_ms = 0.0f;
+	return finish_timing(ctx, false, false, !hits_dev);
+}
+
+int mrt_cast_tiled(mrt_ctx *ctx, const mrt_ray32 *d_rays, mrt_hit32 *d_hits,
+		uint32_t grid_w, uint32_t rows, uint32_t query_mask, int mode)
+{
+	if (!ctx || !d_rays || !d_hits || grid_w == 0) return MRT_ERR_INVALID;
+	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded");
+	if (ctx->pending) return fail(ctx, MRT_ERR_PENDING, "collect the pending dispatch first");
+	if (rows == 0) return MRT_OK;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	mrt::TraceParams p;
+	base_params(ctx, p);
+	p.rays = d_rays; p.hits = d_hits; p.count = (uint64_t)grid_w * rows; p.query_mask = query_mask;
+	p.in_fmt = mrt::IN_RAY32; p.out_fmt = mrt::OUT_HIT32;
+	p.lane_map = ctx->opts.grid_tile == 1 ? mrt::MAP_LINEAR : mrt::MAP_TILE8X8;
+	p.grid_w = grid_w; p.grid_h = rows; p.y0 = 0; p.rows = rows; p.tiles_x = (grid_w + 7u) / 8u;
+	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
+	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	ctx->stats.last_kernel_launches = 1; ctx->stats.rays_cast += p.count;
+	ctx->stats.last_h2d_ms = ctx->stats.last_sort_ms = ctx->stats.last_d2h_ms = 0.0f;
+	return finish_timing(ctx, false, false, false);
+}
+
+int mrt_morton_keys(mrt_ctx *ctx, const mrt_ray32 *d_rays, uint64_t count, uint32_t *d_keys)
+{
+	if (!ctx || !d_rays || !d_keys) return MRT_ERR_INVALID;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	HIP_TRY(ctx, mrt::launch_morton_keys(d_rays, mrt::IN_RAY32, count, d_keys, nullptr, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return MRT_OK;
+}
+
+int mrt_get_stats(mrt_ctx *ctx, mrt_stats *out)
+{
+	if (!ctx || !out) return MRT_ERR_INVALID;
+	*out = ctx->stats;
+	return MRT_OK;
+}
+
+int mrt_device_alloc(mrt_ctx *ctx, size_t bytes, void **d_ptr)
+{
+	if (!ctx || !d_ptr) return MRT_ERR_INVALID;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	if (hipMalloc(d_ptr, bytes ? bytes : 16) != hipSuccess) { *d_ptr = nullptr; return fail(ctx, MRT_ERR_OOM, "device allocation failed"); }
+	return MRT_OK;
+}
+int mrt_device_free(mrt_ctx *ctx, void *d_ptr)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	if (d_ptr) HIP_TRY(ctx, hipFree(d_ptr));
+	return MRT_OK;
+}
+int mrt_memcpy_h2d(mrt_ctx *ctx, void *d_dst, const void *h_src, size_t bytes)
+{
+	if (!ctx || (bytes && (!d_dst || !h_src))) return MRT_ERR_INVALID;
+	HIP_TRY(ctx, hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return MRT_OK;
+}
+int mrt_memcpy_d2h(mrt_ctx *ctx, void *h_dst, const void *d_src, size_t bytes)
+{
+	if (!ctx || (bytes && (!h_dst || !d_src))) return MRT_ERR_INVALID;
+	HIP_TRY(ctx, hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return MRT_OK;
+}
+
+} // extern "C"

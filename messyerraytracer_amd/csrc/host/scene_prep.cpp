@@ -1,0 +1,178 @@
+// scene_prep.cpp — host-side scene preparation for the device layout.
+//
+//  * mrt_make_triangles / mrt_pack_host_triangles: Triangle ctor and the
+//    Triangle -> GPUTrianglePacked loop (src/core/triangle.h:41-51,
+//    src/gpu/gpu_ray_caster.cpp:205-217).
+//  * prepare_scene: TinyBVH BVH2 -> dual-AABB nodes, the conversion half of
+//    GPURayCaster::upload_scene (src/gpu/gpu_ray_caster.cpp:219-311), with the
+//    prim_idx indirection resolved and arrays sized by used_nodes
+//    (defects 1 and 2), validated before anything is
+//    handed to a kernel.
+//  * mrt_camera_look: camera basis of RayTracerDebug::cast_debug_rays
+//    (src/godot/raytracer_debug.cpp:573-583).
+//
+// Compiled with -ffp-contract=off: every rounding is the one written.
+#include <cmath>
+#include <cfloat>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../mrt_internal.h"
+
+namespace {
+
+// godot::Vector3::normalized(): zero stays zero, otherwise divide by the length.
+inline void normalize3(float v[3])
+{
+	float l2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+	if (l2 == 0.0f) { v[0] = v[1] = v[2] = 0.0f; return; }
+	float l = std::sqrt(l2);
+	v[0] /= l; v[1] /= l; v[2] /= l;
+}
+inline void cross3(const float a[3], const float b[3], float r[3])
+{
+	r[0] = a[1] * b[2] - a[2] * b[1];
+	r[1] = a[2] * b[0] - a[0] * b[2];
+	r[2] = a[0] * b[1] - a[1] * b[0];
+}
+
+} // namespace
+
+extern "C" int mrt_make_triangles(const float *verts9, const uint32_t *ids, const uint32_t *layers,
+		uint32_t n_tris, mrt_tri64 *out)
+{
+	if (!verts9 || !out) return MRT_ERR_INVALID;
+	for (uint32_t i = 0; i < n_tris; i++) {
+		const float *a = verts9 + 9 * (size_t)i, *b = a + 3, *c = a + 6;
+		mrt_tri64 &t = out[i];
+		for (int k = 0; k < 3; k++) { t.v0[k] = a[k]; t.edge1[k] = b[k] - a[k]; t.edge2[k] = c[k] - a[k]; }
+		cross3(t.edge1, t.edge2, t.normal);
+		normalize3(t.normal);
+		t.id = ids ? ids[i] : i;
+		t.layers = layers ? layers[i] : 0xFFFFFFFFu;
+		t.pad2 = 0.0f; t.pad3 = 0.0f;
+	}
+	return MRT_OK;
+}
+
+extern "C" int mrt_pack_host_triangles(const mrt_host_tri80 *tris, uint32_t n_tris, mrt_tri64 *out)
+{
+	if (!tris || !out) return MRT_ERR_INVALID;
+	for (uint32_t i = 0; i < n_tris; i++) {
+		const mrt_host_tri80 &t = tris[i];
+		mrt_tri64 &g = out[i];
+		for (int k = 0; k < 3; k++) { g.v0[k] = t.v0[k]; g.edge1[k] = t.edge1[k]; g.edge2[k] = t.edge2[k]; g.normal[k] = t.normal[k]; }
+		g.id = t.id; g.layers = t.layers; g.pad2 = 0.0f; g.pad3 = 0.0f;
+	}
+	return MRT_OK;
+}
+
+extern "C" int mrt_camera_look(mrt_camera *cam, const float origin[3], const float forward[3],
+		uint32_t grid_w, uint32_t grid_h, float fov_degrees)
+{
+	if (!cam || !origin || !forward || grid_w == 0 || grid_h == 0) return MRT_ERR_INVALID;
+	float fwd[3] = { forward[0], forward[1], forward[2] };
+	normalize3(fwd);
+	float hint[3] = { 0.0f, 1.0f, 0.0f };
+	if (std::fabs(fwd[0] * hint[0] + fwd[1] * hint[1] + fwd[2] * hint[2]) > 0.99f) { hint[0] = 1.0f; hint[1] = 0.0f; }
+	float right[3], up[3];
+	cross3(fwd, hint, right); normalize3(right);
+	cross3(right, fwd, up); normalize3(up);
+	const float half_fov_rad = (fov_degrees * 0.5f) * (float)(3.14159265358979323846 / 180.0); // Math::deg_to_rad
+	const float half_w = std::tan(half_fov_rad);
+	const float half_h = half_w * ((float)grid_h / (float)grid_w);
+	for (int k = 0; k < 3; k++) { cam->origin[k] = origin[k]; cam->fwd[k] = fwd[k]; cam->right[k] = right[k]; cam->up[k] = up[k]; }
+	cam->half_w = half_w; cam->half_h = half_h;
+	cam->t_min = 0.001f; cam->t_max = FLT_MAX; // Ray(origin, dir) defaults, src/core/ray.h:59
+	return MRT_OK;
+}
+
+namespace mrt {
+
+int prepare_scene(const mrt_tri64 *tris, uint32_t n_tris, const mrt_bvh_node32 *nodes, uint32_t used_nodes,
+		const uint32_t *prim_idx, DeviceSceneHost *out, char *err, size_t err_len)
+{
+	auto fail = [&](int code, const char *msg) { if (err && err_len) std::snprintf(err, err_len, "%s", msg); return code; };
+	if (!tris || !nodes || !prim_idx || !out) return fail(MRT_ERR_INVALID, "upload_scene: null argument");
+	if (n_tris == 0 || used_nodes == 0) return fail(MRT_ERR_INVALID, "upload_scene: empty scene");
+	if (n_tris >= 0x7FFFFFFFu) return fail(MRT_ERR_UNSUPPORTED, "upload_scene: more than 2^31-1 triangles");
+
+	// ---- leaf-ordered triangle arrays: slot k holds triangle prim_idx[k] ----
+	TriHot *hot = (TriHot *)std::malloc((size_t)n_tris * sizeof(TriHot));
+	TriCold *cold = (TriCold *)std::malloc((size_t)n_tris * sizeof(TriCold));
+	if (!hot || !cold) { std::free(hot); std::free(cold); return fail(MRT_ERR_OOM, "upload_scene: out of host memory"); }
+	for (uint32_t k = 0; k < n_tris; k++) {
+		const uint32_t pi = prim_idx[k];
+		if (pi >= n_tris) { std::free(hot); std::free(cold); return fail(MRT_ERR_BAD_BVH, "upload_scene: prim_idx entry out of range"); }
+		const mrt_tri64 &t = tris[pi];
+		TriHot &h = hot[k];
+		for (int c = 0; c < 3; c++) { h.v0[c] = t.v0[c]; h.e1[c] = t.edge1[c]; h.e2[c] = t.edge2[c]; cold[k].normal[c] = t.normal[c]; }
+		h.id = t.id; h.layers = t.layers; h.flags = 0u; cold[k].pad = 0u;
+	}
+
+	auto leaf_ok = [&](const mrt_bvh_node32 &n) { return n.tri_count > 0 && n.left_first < n_tris && n.tri_count <= n_tris - n.left_first; };
+	auto mark_leaf = [&](uint32_t first, uint32_t count) { hot[first + count - 1].flags |= kLastInLeaf; return kLeafBit | first; };
+
+	std::vector<DevNode> dev;
+	uint32_t depth = 0;
+	const mrt_bvh_node32 &root = nodes[0];
+	if (root.tri_count > 0) {
+		// Root is a leaf (tiny scene).  The reference wraps it with a NaN right box
+		// (gpu_ray_caster.cpp:255-271); v_min/v_max drop NaNs, so the range is split
+		// into two leaf children that both carry the root box instead.
+		if (!leaf_ok(root)) { std::free(hot); std::free(cold); return fail(MRT_ERR_BAD_BVH, "upload_scene: root leaf range out of bounds"); }
+		DevNode g{};
+		const uint32_t lc = (root.tri_count + 1) / 2, rc = root.tri_count - lc;
+		for (int c = 0; c < 3; c++) { g.lmin[c] = g.rmin[c] = root.aabb_min[c]; g.lmax[c] = g.rmax[c] = root.aabb_max[c]; }
+		g.left_ref = mark_leaf(root.left_first, lc); g.left_count = lc;
+		if (rc == 0) { g.right_ref = g.left_ref; g.right_count = lc; }
+		else { g.right_ref = mark_leaf(root.left_first + lc, rc); g.right_count = rc; }
+		dev.push_back(g);
+		depth = 1;
+	} else {
+		// DFS preorder numbering of internal nodes, with cycle / range validation.
+		std::vector<uint32_t> map(used_nodes, 0xFFFFFFFFu);
+		struct Item { uint32_t node, d; };
+		std::vector<Item> stack;
+		stack.push_back({ 0u, 1u });
+		uint32_t n_wide = 0;
+		std::vector<uint32_t> order;
+		while (!stack.empty()) {
+			const Item it = stack.back(); stack.pop_back();
+			if (map[it.node] != 0xFFFFFFFFu) { std::free(hot); std::free(cold); return fail(MRT_ERR_BAD_BVH, "upload_scene: BVH node referenced twice"); }
+			map[it.node] = n_wide++;
+			order.push_back(it.node);
+			if (it.d > depth) depth = it.d;
+			const uint32_t l = nodes[it.node].left_first, r = l + 1;
+			if (l == 0 || r >= used_nodes || r < l) { std::free(hot); std::free(cold); return fail(MRT_ERR_BAD_BVH, "upload_scene: child index out of range"); }
+			if (nodes[r].tri_count == 0) stack.push_back({ r, it.d + 1 });
+			else if (!leaf_ok(nodes[r])) { std::free(hot); std::free(cold); return fail(MRT_ERR_BAD_BVH, "upload_scene: leaf range out of bounds"); }
+			if (nodes[l].tri_count == 0) stack.push_back({ l, it.d + 1 });
+			else if (!leaf_ok(nodes[l])) { std::free(hot); std::free(cold); return fail(MRT_ERR_BAD_BVH, "upload_scene: leaf range out of bounds"); }
+		}
+		dev.resize(n_wide);
+		for (uint32_t w = 0; w < n_wide; w++) {
+			const mrt_bvh_node32 &n = nodes[order[w]];
+			const mrt_bvh_node32 &lc = nodes[n.left_first], &rc = nodes[n.left_first + 1];
+			DevNode &g = dev[w];
+			for (int c = 0; c < 3; c++) {
+				g.lmin[c] = lc.aabb_min[c]; g.lmax[c] = lc.aabb_max[c];
+				g.rmin[c] = rc.aabb_min[c]; g.rmax[c] = rc.aabb_max[c];
+			}
+			if (lc.tri_count > 0) { g.left_ref = mark_leaf(lc.left_first, lc.tri_count); g.left_count = lc.tri_count; }
+			else { g.left_ref = map[n.left_first]; g.left_count = 0; }
+			if (rc.tri_count > 0) { g.right_ref = mark_leaf(rc.left_first, rc.tri_count); g.right_count = rc.tri_count; }
+			else { g.right_ref = map[n.left_first + 1]; g.right_count = 0; }
+		}
+	}
+	out->n_nodes = (uint32_t)dev.size();
+	out->nodes = (DevNode *)std::malloc(dev.size() * sizeof(DevNode));
+	if (!out->nodes) { std::free(hot); std::free(cold); return fail(MRT_ERR_OOM, "upload_scene: out of host memory"); }
+	std::memcpy(out->nodes, dev.data(), dev.size() * sizeof(DevNode));
+	out->hot = hot; out->cold = cold; out->n_tris = n_tris;
+	out->depth = depth + 1; // one pending entry per wide node on the current path + the sentinel
+	return MRT_OK;
+}
+
+} // namespace mrt

@@ -1,0 +1,328 @@
+// kernels.hip — gfx950 (CDNA4, wave64) kernels of the batch ray-cast path.
+//
+// Replaces the reference's GLSL compute shader
+// src/gpu/shaders/bvh_traverse.comp.glsl (one thread = one ray, stack-based
+// ordered BVH2 traversal over 64-byte dual-AABB nodes, slab test, Moller-
+// Trumbore) and the two host conversion loops around it
+// (src/gpu/gpu_ray_caster.cpp:639-650, 442-456), which run on the device here.
+//
+// Arithmetic is the canonical form documented in DESIGN.md ("Arithmetic"):
+// compiled with -ffp-contract=off, every fused operation is an explicit
+// __builtin_fmaf, so results are bit-identical to oracle/mrt_oracle.c.
+#include <hip/hip_runtime.h>
+#include <cfloat>
+#include "mrt_internal.h"
+
+namespace mrt {
+
+#define MRT_WG 256
+#define MRT_WAVE 64
+
+// ---- canonical arithmetic ------------------------------------------------------
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+__device__ __forceinline__ float dot3(float ax, float ay, float az, float bx, float by, float bz)
+{
+	return fma_(ax, bx, fma_(ay, by, az * bz));
+}
+// safe_inv_direction, bvh_traverse.comp.glsl:137-145 == Ray::_precompute, src/core/ray.h:78-89
+__device__ __forceinline__ float safe_inv(float d)
+{
+	const float eps = 1e-9f;
+	const float big = 1.0f / eps;
+	return __builtin_fabsf(d) > eps ? 1.0f / d : (d >= 0.0f ? big : -big);
+}
+
+struct RayRegs {
+	float ox, oy, oz, dx, dy, dz, t_min, t_max;
+};
+
+// ---- lane -> ray mapping ---------------------------------------------------------
+// MAP_LINEAR: thread g traces ray g (or perm[g]).  MAP_TILE8X8: a wave owns an
+// 8x8 pixel tile of the row-major grid so its 64 rays share most of their path.
+__device__ __forceinline__ bool lane_ray_index(const TraceParams &p, uint32_t block, uint64_t &ray_idx, uint32_t &px, uint32_t &py)
+{
+	const uint64_t g = (uint64_t)block * MRT_WG + threadIdx.x;
+	if (p.lane_map == MAP_TILE8X8) {
+		const uint64_t tile = g >> 6;
+		const uint32_t l = (uint32_t)g & 63u;
+		const uint32_t tx = (uint32_t)(tile % p.tiles_x), ty = (uint32_t)(tile / p.tiles_x);
+		px = tx * 8u + (l & 7u);
+		py = ty * 8u + (l >> 3);
+		if (px >= p.grid_w || py >= p.rows) return false;
+		ray_idx = (uint64_t)py * p.grid_w + px;
+		return true;
+	}
+	if (g >= p.count) return false;
+	ray_idx = p.perm ? (uint64_t)p.perm[g] : g;
+	if (p.in_fmt == IN_GRID) { px = (uint32_t)(ray_idx % p.grid_w); py = (uint32_t)(ray_idx / p.grid_w); }
+	return true;
+}
+
+// Primary-ray grid: RayTracerDebug::cast_debug_rays, src/godot/raytracer_debug.cpp:585-596.
+// Basis / half extents come precomputed from the host (mrt_camera_look, :573-583).
+__device__ __forceinline__ void grid_ray(const TraceParams &p, uint32_t px, uint32_t py, RayRegs &r)
+{
+	const mrt_camera &c = p.cam;
+	const float u = (2.0f * ((float)px + 0.5f) / (float)p.grid_w - 1.0f) * c.half_w;
+	const float v = (2.0f * ((float)(py + p.y0) + 0.5f) / (float)p.grid_h - 1.0f) * c.half_h;
+	float dx = c.fwd[0] + c.right[0] * u + c.up[0] * v;
+	float dy = c.fwd[1] + c.right[1] * u + c.up[1] * v;
+	float dz = c.fwd[2] + c.right[2] * u + c.up[2] * v;
+	const float l2 = dx * dx + dy * dy + dz * dz;
+	if (l2 == 0.0f) { dx = dy = dz = 0.0f; }
+	else { const float l = __builtin_sqrtf(l2); dx /= l; dy /= l; dz /= l; }
+	r.ox = c.origin[0]; r.oy = c.origin[1]; r.oz = c.origin[2];
+	r.dx = dx; r.dy = dy; r.dz = dz;
+	r.t_min = c.t_min; r.t_max = c.t_max;
+}
+
+__device__ __forceinline__ void load_ray(const TraceParams &p, uint64_t idx, uint32_t px, uint32_t py, RayRegs &r)
+{
+	if (p.in_fmt == IN_GRID) { grid_ray(p, px, py, r); return; }
+	float ox, oy, oz, dx, dy, dz, t0, t1;
+	if (p.in_fmt == IN_HOST60) { // Ray -> GPURayPacked, gpu_ray_caster.cpp:643-650
+		const float *h = reinterpret_cast<const float *>(p.rays) + idx * 15u;
+		ox = h[0]; oy = h[1]; oz = h[2]; dx = h[3]; dy = h[4]; dz = h[5];
+		t0 = h[12]; t1 = h[13];
+	} else {
+		const float4 *q = reinterpret_cast<const float4 *>(p.rays) + idx * 2u;
+		const float4 a = q[0], b = q[1];
+		ox = a.x; oy = a.y; oz = a.z; t1 = a.w;
+		dx = b.x; dy = b.y; dz = b.z; t0 = b.w;
+	}
+	r.ox = ox; r.oy = oy; r.oz = oz; r.dx = dx; r.dy = dy; r.dz = dz; r.t_min = t0; r.t_max = t1;
+}
+
+// Result store: bvh_traverse.comp.glsl:322-327, plus the readback conversion of
+// gpu_ray_caster.cpp:442-456 (OUT_HOST44) / :482-487 (OUT_BOOL8) fused in.
+__device__ __forceinline__ void store_hit(const TraceParams &p, uint64_t idx, const RayRegs &r,
+		float t, int32_t prim, float u, float v, float nx, float ny, float nz, uint32_t layers)
+{
+	if (p.out_fmt == OUT_BOOL8) { reinterpret_cast<uint8_t *>(p.hits)[idx] = prim >= 0 ? 1 : 0; return; }
+	if (p.out_fmt == OUT_HOST44) {
+		float *h = reinterpret_cast<float *>(p.hits) + idx * 11u;
+		uint32_t *hu = reinterpret_cast<uint32_t *>(h);
+		if (prim >= 0) {
+			h[0] = t;
+			h[1] = r.ox + r.dx * t; h[2] = r.oy + r.dy * t; h[3] = r.oz + r.dz * t;
+			h[4] = nx; h[5] = ny; h[6] = nz; h[7] = u; h[8] = v;
+			hu[9] = (uint32_t)prim; hu[10] = layers;
+		} else { // Intersection::set_miss on a default-constructed record
+			h[0] = FLT_MAX; h[1] = h[2] = h[3] = 0.0f; h[4] = h[5] = h[6] = 0.0f; h[7] = h[8] = 0.0f;
+			hu[9] = 0xFFFFFFFFu; hu[10] = 0u;
+		}
+		return;
+	}
+	float4 *q = reinterpret_cast<float4 *>(p.hits) + idx * 2u;
+	float4 a, b;
+	a.x = t; a.y = __int_as_float(prim); a.z = u; a.w = v;
+	b.x = nx; b.y = ny; b.z = nz; b.w = __uint_as_float(layers);
+	q[0] = a; q[1] = b;
+}
+
+// ---- the traversal kernel: one lane = one ray -------------------------------------
+// LDS: per-lane stack, entry d of lane l at dword d*64 + l of the wave's region
+// (conflict-free: the 64 lanes of a push/pop hit 64 consecutive dwords).
+template <bool ANY_HIT, bool COUNT>
+__global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
+{
+	extern __shared__ uint32_t lds_stack[];
+	uint32_t block = blockIdx.x;
+	if (p.xcd_swizzle) { // contiguous band of the batch per XCD (blocks are dealt round-robin over 8 XCDs)
+		const uint32_t per = gridDim.x >> 3;
+		if (block < (per << 3)) block = (block & 7u) * per + (block >> 3);
+	}
+	uint64_t ray_idx = 0; uint32_t px = 0, py = 0;
+	if (!lane_ray_index(p, block, ray_idx, px, py)) return;
+	RayRegs r;
+	load_ray(p, ray_idx, px, py, r);
+
+	float best_t = r.t_max, best_u = 0.0f, best_v = 0.0f;
+	uint32_t best_slot = 0xFFFFFFFFu;
+	uint32_t n_nodes = 0, n_tris = 0, max_sp = 0;
+
+	if (!(r.t_min >= r.t_max)) { // degenerate rays are misses, glsl:214-222
+		const float ix = safe_inv(r.dx), iy = safe_inv(r.dy), iz = safe_inv(r.dz);
+		const float nrx = -(r.ox * ix), nry = -(r.oy * iy), nrz = -(r.oz * iz);
+		const uint32_t lane = threadIdx.x & (MRT_WAVE - 1);
+		const uint32_t wave = threadIdx.x / MRT_WAVE;
+		uint32_t sp = wave * (p.stack_depth * MRT_WAVE) + lane; // dword index of this lane's stack bottom
+		lds_stack[sp] = kSentinel; sp += MRT_WAVE;
+		uint32_t cur = 0; // the root is always a wide node (root leaves are wrapped on the host)
+		const float4 *nodes = reinterpret_cast<const float4 *>(p.nodes);
+		const float4 *hot = reinterpret_cast<const float4 *>(p.tri_hot);
+
+		while (cur != kSentinel) {
+			// ---- inner nodes: glsl:243-318 ----
+			while (cur < kSentinel) {
+				const float4 *n = nodes + (size_t)cur * 4u;
+				const float4 a = n[0], b = n[1], c = n[2], d = n[3];
+				if (COUNT) n_nodes++;
+				// ray_aabb (glsl:84-99) for both children, clamped to [t_min, best_t]
+				const float l0x = fma_(a.x, ix, nrx), l1x = fma_(b.x, ix, nrx);
+				const float l0y = fma_(a.y, iy, nry), l1y = fma_(b.y, iy, nry);
+				const float l0z = fma_(a.z, iz, nrz), l1z = fma_(b.z, iz, nrz);
+				const float r0x = fma_(c.x, ix, nrx), r1x = fma_(d.x, ix, nrx);
+				const float r0y = fma_(c.y, iy, nry), r1y = fma_(d.y, iy, nry);
+				const float r0z = fma_(c.z, iz, nrz), r1z = fma_(d.z, iz, nrz);
+				const float tl = fmaxf(fmaxf(fminf(l0x, l1x), fminf(l0y, l1y)), fmaxf(fminf(l0z, l1z), r.t_min));
+				const float tlx = fminf(fminf(fmaxf(l0x, l1x), fmaxf(l0y, l1y)), fminf(fmaxf(l0z, l1z), best_t));
+				const float tr = fmaxf(fmaxf(fminf(r0x, r1x), fminf(r0y, r1y)), fmaxf(fminf(r0z, r1z), r.t_min));
+				const float trx = fminf(fminf(fmaxf(r0x, r1x), fmaxf(r0y, r1y)), fminf(fmaxf(r0z, r1z), best_t));
+				const bool hl = tl <= tlx, hr = tr <= trx;
+				const uint32_t lref = __float_as_uint(a.w), rref = __float_as_uint(b.w);
+				if (hl && hr) { // near child first, far child pushed (glsl:290-305)
+					const bool left_near = tl < tr;
+					cur = left_near ? lref : rref;
+					lds_stack[sp] = left_near ? rref : lref; sp += MRT_WAVE;
+					if (COUNT) { const uint32_t dpt = (sp - lane) / MRT_WAVE - wave * p.stack_depth; max_sp = dpt > max_sp ? dpt : max_sp; }
+				} else if (hl) cur = lref;
+				else if (hr) cur = rref;
+				else { sp -= MRT_WAVE; cur = lds_stack[sp]; }
+			}
+			// ---- leaves: INTERSECT_LEAF, glsl:166-192 ----
+			while (cur >= kLeafBit) {
+				uint32_t slot = cur & 0x7FFFFFFFu;
+				bool last;
+				do {
+					const float4 *t3 = hot + (size_t)slot * 3u;
+					const float4 q0 = t3[0], q1 = t3[1], q2 = t3[2];
+					last = (__float_as_uint(q2.w) & kLastInLeaf) != 0u;
+					if ((__float_as_uint(q1.w) & p.query_mask) != 0u) {
+						if (COUNT) n_tris++;
+						// ray_triangle, glsl:105-131 == Triangle::intersect, src/core/triangle.h:56-105
+						const float pvx = fma_(r.dy, q2.z, -(r.dz * q2.y));
+						const float pvy = fma_(r.dz, q2.x, -(r.dx * q2.z));
+						const float pvz = fma_(r.dx, q2.y, -(r.dy * q2.x));
+						const float det = dot3(q1.x, q1.y, q1.z, pvx, pvy, pvz);
+						if (!(__builtin_fabsf(det) < 1e-8f)) {
+							const float inv_det = 1.0f / det;
+							const float tvx = r.ox - q0.x, tvy = r.oy - q0.y, tvz = r.oz - q0.z;
+							const float u = dot3(tvx, tvy, tvz, pvx, pvy, pvz) * inv_det;
+							if (!(u < 0.0f || u > 1.0f)) {
+								const float qvx = fma_(tvy, q1.z, -(tvz * q1.y));
+								const float qvy = fma_(tvz, q1.x, -(tvx * q1.z));
+								const float qvz = fma_(tvx, q1.y, -(tvy * q1.x));
+								const float v = dot3(r.dx, r.dy, r.dz, qvx, qvy, qvz) * inv_det;
+								if (!(v < 0.0f || u + v > 1.0f)) {
+									const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
+									if (!(t < r.t_min || t >= best_t)) {
+										best_t = t; best_u = u; best_v = v; best_slot = slot;
+										if (ANY_HIT) last = true;
+									}
+								}
+							}
+						}
+					}
+					slot++;
+				} while (!last);
+				if (ANY_HIT && best_slot != 0xFFFFFFFFu) { cur = kSentinel; break; }
+				sp -= MRT_WAVE; cur = lds_stack[sp];
+			}
+		}
+	}
+
+	// ---- result: glsl:322-327 ----
+	int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
+	if (best_slot != 0xFFFFFFFFu) {
+		prim = (int32_t)p.tri_hot[best_slot].id;
+		layers = p.tri_hot[best_slot].layers;
+		const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
+		nx = nn.x; ny = nn.y; nz = nn.z;
+	}
+	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers);
+
+	if (COUNT) {
+		atomicAdd(&p.counters[0], 1ull);
+		atomicAdd(&p.counters[1], (unsigned long long)n_tris);
+		atomicAdd(&p.counters[2], (unsigned long long)n_nodes);
+		if (prim >= 0) atomicAdd(&p.counters[3], 1ull);
+		atomicMax(&p.counters[4], (unsigned long long)max_sp);
+	}
+}
+
+// ---- standalone ray generation (mrt_generate_grid) ---------------------------------
+__global__ __launch_bounds__(MRT_WG) void grid_rays_kernel(const TraceParams p, mrt_ray32 *out)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * MRT_WG + threadIdx.x;
+	if (g >= p.count) return;
+	RayRegs r;
+	grid_ray(p, (uint32_t)(g % p.grid_w), (uint32_t)(g / p.grid_w), r);
+	float4 *q = reinterpret_cast<float4 *>(out) + g * 2u;
+	float4 a, b;
+	a.x = r.ox; a.y = r.oy; a.z = r.oz; a.w = r.t_max;
+	b.x = r.dx; b.y = r.dy; b.z = r.dz; b.w = r.t_min;
+	q[0] = a; q[1] = b;
+}
+
+// ---- Morton keys: src/dispatch/ray_sort.h:41-76 -------------------------------------
+__device__ __forceinline__ uint32_t spread10(uint32_t v)
+{
+	v &= 0x000003FFu;
+	v = (v | (v << 16)) & 0x030000FFu;
+	v = (v | (v << 8)) & 0x0300F00Fu;
+	v = (v | (v << 4)) & 0x030C30C3u;
+	v = (v | (v << 2)) & 0x09249249u;
+	return v;
+}
+__device__ __forceinline__ uint32_t quant10(float v)
+{
+	float n = (v + 1.0f) * 0.5f;
+	n = fmaxf(0.0f, fminf(1.0f, n));
+	return (uint32_t)(n * 1023.0f);
+}
+__global__ __launch_bounds__(MRT_WG) void morton_keys_kernel(const void *rays, uint32_t in_fmt, uint64_t count,
+		uint32_t *keys, uint32_t *index)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * MRT_WG + threadIdx.x;
+	if (g >= count) return;
+	float dx, dy, dz;
+	if (in_fmt == IN_HOST60) {
+		const float *h = reinterpret_cast<const float *>(rays) + g * 15u;
+		dx = h[3]; dy = h[4]; dz = h[5];
+	} else {
+		const float4 b = reinterpret_cast<const float4 *>(rays)[g * 2u + 1u];
+		dx = b.x; dy = b.y; dz = b.z;
+	}
+	keys[g] = (spread10(quant10(dx)) << 2) | (spread10(quant10(dy)) << 1) | spread10(quant10(dz));
+	if (index) index[g] = (uint32_t)g;
+}
+
+// ---- launch wrappers (called from api.hip) -------------------------------------------
+hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream)
+{
+	uint64_t threads;
+	if (p.lane_map == MAP_TILE8X8) threads = (uint64_t)p.tiles_x * ((p.rows + 7u) / 8u) * 64u;
+	else threads = p.count;
+	if (threads == 0) return hipSuccess;
+	const uint64_t blocks = (threads + MRT_WG - 1) / MRT_WG;
+	if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+	const size_t lds = (size_t)(MRT_WG / MRT_WAVE) * p.stack_depth * MRT_WAVE * sizeof(uint32_t);
+	dim3 grid((uint32_t)blocks), wg(MRT_WG);
+	if (any_hit) {
+		if (count) hipLaunchKernelGGL((trace_lane_kernel<true, true>), grid, wg, lds, stream, p);
+		else hipLaunchKernelGGL((trace_lane_kernel<true, false>), grid, wg, lds, stream, p);
+	} else {
+		if (count) hipLaunchKernelGGL((trace_lane_kernel<false, true>), grid, wg, lds, stream, p);
+		else hipLaunchKernelGGL((trace_lane_kernel<false, false>), grid, wg, lds, stream, p);
+	}
+	return hipGetLastError();
+}
+
+hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t stream)
+{
+	if (p.count == 0) return hipSuccess;
+	const uint64_t blocks = (p.count + MRT_WG - 1) / MRT_WG;
+	hipLaunchKernelGGL(grid_rays_kernel, dim3((uint32_t)blocks), dim3(MRT_WG), 0, stream, p, out);
+	return hipGetLastError();
+}
+
+hipError_t launch_morton_keys(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t *keys, uint32_t *index, hipStream_t stream)
+{
+	if (count == 0) return hipSuccess;
+	const uint64_t blocks = (count + MRT_WG - 1) / MRT_WG;
+	hipLaunchKernelGGL(morton_keys_kernel, dim3((uint32_t)blocks), dim3(MRT_WG), 0, stream, rays, in_fmt, count, keys, index);
+	return hipGetLastError();
+}
+
+} // namespace mrt

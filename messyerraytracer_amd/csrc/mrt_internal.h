@@ -1,0 +1,80 @@
+// mrt_internal.h — shared between the host-side scene preparation and the HIP
+// kernels of libmrt_hip.so.  Not part of the C-ABI.
+#pragma once
+#include <cstdint>
+#include "../../include/mrt_hip.h"
+
+static_assert(sizeof(mrt_ray32) == 32, "GPURayPacked must be 32 bytes (src/api/gpu_types.h:70)");
+static_assert(sizeof(mrt_hit32) == 32, "GPUIntersectionPacked must be 32 bytes (src/api/gpu_types.h:93)");
+static_assert(sizeof(mrt_tri64) == 64, "GPUTrianglePacked must be 64 bytes (src/api/gpu_types.h:51)");
+static_assert(sizeof(mrt_bvh_node32) == 32, "GPUBVHNodePacked must be 32 bytes (src/api/gpu_types.h:127)");
+static_assert(sizeof(mrt_bvh_node_wide64) == 64, "GPUBVHNodeWide must be 64 bytes (src/gpu/gpu_structs.h:47)");
+static_assert(sizeof(mrt_host_ray60) == 60, "Ray must be 60 bytes (src/core/ray.h:25-51, precision=single)");
+static_assert(sizeof(mrt_host_hit44) == 44, "Intersection must be 44 bytes (src/core/intersection.h:16-40)");
+static_assert(sizeof(mrt_host_tri80) == 80, "Triangle must be 80 bytes (src/core/triangle.h:22-39)");
+
+namespace mrt {
+
+// ---- device scene layout (HBM) ------------------------------------------------
+// Node: the reference's 64-byte dual-AABB node with the child encoding folded
+// into one 32-bit reference per child:
+//   ref <  0x7FFFFFFF : index of a wide node
+//   ref == 0x7FFFFFFF : sentinel (bottom of every traversal stack)
+//   ref >= 0x80000000 : leaf; low 31 bits = first slot in the leaf-ordered
+//                       triangle arrays; the leaf's last triangle carries
+//                       kLastInLeaf in TriHot::flags.
+struct alignas(16) DevNode {
+	float lmin[3]; uint32_t left_ref;
+	float lmax[3]; uint32_t right_ref;
+	float rmin[3]; uint32_t left_count;   // counts kept for validation / stats only
+	float rmax[3]; uint32_t right_count;
+};
+static_assert(sizeof(DevNode) == 64, "DevNode must be 64 bytes");
+
+// Triangle, split hot/cold: traversal reads 48 B per test, the 16-byte normal
+// row is read once per ray for the winning triangle.
+struct alignas(16) TriHot {
+	float v0[3]; uint32_t id;
+	float e1[3]; uint32_t layers;
+	float e2[3]; uint32_t flags;
+};
+static_assert(sizeof(TriHot) == 48, "TriHot must be 48 bytes");
+struct alignas(16) TriCold { float normal[3]; uint32_t pad; };
+
+constexpr uint32_t kSentinel = 0x7FFFFFFFu;
+constexpr uint32_t kLeafBit = 0x80000000u;
+constexpr uint32_t kLastInLeaf = 1u;
+
+enum InFmt : uint32_t { IN_RAY32 = 0, IN_HOST60 = 1, IN_GRID = 2 };
+enum OutFmt : uint32_t { OUT_HIT32 = 0, OUT_HOST44 = 1, OUT_BOOL8 = 2 };
+enum LaneMap : uint32_t { MAP_LINEAR = 0, MAP_TILE8X8 = 1 };
+
+struct TraceParams {
+	const DevNode *nodes;
+	const TriHot *tri_hot;
+	const TriCold *tri_cold;
+	const void *rays;          // IN_RAY32 / IN_HOST60 (device)
+	void *hits;                // device
+	const uint32_t *perm;      // optional: lane g traces ray perm[g], writes hits[perm[g]]
+	unsigned long long *counters; // COUNT variants: rays, tri_tests, node_visits, hits, max_stack
+	uint64_t count;            // number of rays
+	uint32_t query_mask;
+	uint32_t in_fmt, out_fmt, lane_map;
+	uint32_t grid_w, grid_h, y0, rows; // IN_GRID / MAP_TILE8X8: rows [y0, y0+rows) of a grid_w x grid_h grid
+	uint32_t tiles_x;          // ceil(grid_w / 8)
+	uint32_t stack_depth;      // LDS stack entries per lane
+	uint32_t xcd_swizzle;      // 1: remap blockIdx so each XCD owns a contiguous band
+	mrt_camera cam;
+};
+
+// host-side preparation (scene_prep.cpp)
+struct DeviceSceneHost {
+	DevNode *nodes = nullptr; uint32_t n_nodes = 0;
+	TriHot *hot = nullptr; TriCold *cold = nullptr; uint32_t n_tris = 0;
+	uint32_t depth = 0;         // max stack entries any traversal can need (incl. sentinel)
+};
+// Returns MRT_OK or an error; on success arrays are malloc'ed (free with free()).
+int prepare_scene(const mrt_tri64 *tris, uint32_t n_tris, const mrt_bvh_node32 *nodes, uint32_t used_nodes,
+		const uint32_t *prim_idx, DeviceSceneHost *out, char *err, size_t err_len);
+
+} // namespace mrt

@@ -1,0 +1,115 @@
+"""CPU-side checks of the C-ABI library: it loads, exports every symbol the header
+declares, and its host-side functions (triangle packing, BVH builder, camera)
+equal the oracle.  No compute entry point is called (there is no GPU here)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+from messyerraytracer_amd import capi, synth, types as T
+from oracle import pyoracle as po
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "mrt_hip.h")).read()
+    declared = sorted(set(re.findall(r"^(?:int|void|uint32_t|const char \*)\s*(mrt_[a-z0-9_]+)\(", hdr, re.M)))
+    assert declared, "no declarations parsed"
+    assert sorted(capi.SYMBOLS) == declared, "capi.SYMBOLS out of sync with include/mrt_hip.h"
+    L = capi.load()
+    for s in declared:
+        assert hasattr(L, s), f"libmrt_hip.so does not export {s}"
+    assert L.mrt_version() == (0 << 16) | 1
+    assert L.mrt_status_string(0) == b"ok"
+    assert L.mrt_status_string(capi.ERR_PENDING) != L.mrt_status_string(capi.ERR_NOT_PENDING)
+
+
+def test_struct_sizes_match_reference_layouts():
+    assert C.sizeof(capi.Options) == 64
+    assert C.sizeof(capi.Camera) == 64
+    for dt, size in ((T.RAY32, 32), (T.HIT32, 32), (T.TRI64, 64), (T.NODE32, 32), (T.WIDE64, 64),
+                     (T.HOST_RAY60, 60), (T.HOST_HIT44, 44), (T.HOST_TRI80, 80)):
+        assert dt.itemsize == size
+
+
+def test_null_arguments_are_rejected_not_crashed(built):
+    L = capi.load()
+    assert L.mrt_make_triangles(None, None, None, 1, None) == capi.ERR_INVALID
+    assert L.mrt_bvh2_build(None, 0, None, None, None, 1) == capi.ERR_INVALID
+    assert L.mrt_camera_look(None, None, None, 0, 0, 0.0) == capi.ERR_INVALID
+    assert L.mrt_create(0, None, None) == capi.ERR_INVALID
+    assert L.mrt_cast(None, None, None, 0, 0, 0, 0) == capi.ERR_INVALID
+    assert L.mrt_has_pending(None) == 0 and L.mrt_is_available(None) == 0
+    L.mrt_destroy(None)  # no-op
+
+
+def test_create_without_gpu_fails_loudly(built):
+    """No silent CPU fallback: without a device mrt_create reports MRT_ERR_NO_DEVICE."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    with pytest.raises(capi.MrtError) as e:
+        capi.Context(0)
+    assert e.value.status == capi.ERR_NO_DEVICE
+
+
+@pytest.mark.parametrize("n,s,seed", [(1, 0.5, 1), (2, 0.5, 2), (3, 0.5, 3), (7, 0.5, 4), (1000, 0.5, 1), (60000, 0.15, 7)])
+def test_builder_equals_oracle_builder(built, n, s, seed):
+    """mrt_bvh2_build == the restatement of tinybvh::BVH::Build, for any thread count."""
+    v = synth.soup(n, s, seed)
+    v4 = T.verts4_from_verts9(v)
+    on, op, ou = po.bvh2_build(v4)
+    for threads in (1, 3, 8):
+        pn, pp, pu = capi.bvh2_build(v4, threads)
+        assert pu == ou
+        assert pn.tobytes() == on.tobytes()
+        assert np.array_equal(pp, op)
+
+
+def test_builder_degenerate_inputs(built):
+    # all triangles identical: SAH cannot split; one leaf holding everything
+    one = synth.soup(1, 0.5, 3)
+    v = np.repeat(one, 40, axis=0)
+    v4 = T.verts4_from_verts9(v)
+    pn, pp, pu = capi.bvh2_build(v4, 2)
+    on, op, ou = po.bvh2_build(v4)
+    assert pu == ou == 2 and pn[0]["tri_count"] == 40 and pn.tobytes() == on.tobytes()
+    # flat scene (zero extent on z)
+    v = synth.soup(500, 0.5, 8)
+    v[:, :, 2] = 1.0
+    v4 = T.verts4_from_verts9(v)
+    pn, pp, pu = capi.bvh2_build(v4, 4)
+    on, op, ou = po.bvh2_build(v4)
+    assert pn.tobytes() == on.tobytes() and np.array_equal(pp, op)
+
+
+def test_triangles_and_camera_equal_oracle(built):
+    v = synth.soup(5000, 0.3, 11)
+    ids = np.arange(5000, dtype=np.uint32)[::-1].copy()
+    layers = (np.arange(5000, dtype=np.uint32) % 7) + 1
+    assert capi.make_triangles(v, ids, layers).tobytes() == po.make_triangles(v, ids, layers).tobytes()
+    for fwd in ((0, 0, 1), (0, 0, -1), (0, 1, 0), (0.3, -0.2, 0.9), (0, -1, 1e-3)):
+        for (w, h, fov) in ((16, 12, 60.0), (4096, 4096, 50.0), (1920, 1080, 75.0)):
+            cam = capi.camera_look((1, 2, 3), fwd, w, h, fov)
+            f, r, u, hw, hh = po.camera_basis(fwd, w, h, fov)
+            assert np.array_equal(np.array(cam.fwd[:], np.float32), f)
+            assert np.array_equal(np.array(cam.right[:], np.float32), r)
+            assert np.array_equal(np.array(cam.up[:], np.float32), u)
+            assert np.float32(cam.half_w) == hw and np.float32(cam.half_h) == hh
+            assert cam.t_min == np.float32(0.001) and cam.t_max == T.FLT_MAX
+
+
+def test_product_does_not_reference_the_oracle():
+    """The product path may not import, link or call anything under oracle/."""
+    pkg = os.path.join(ROOT, "messyerraytracer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                assert "pyoracle" not in text and "liboracle" not in text and "mrt_oracle.h" not in text \
+                    and "libmrt_ref" not in text, f"{fn} references the oracle"
+    import subprocess
+    out = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out

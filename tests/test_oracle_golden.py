@@ -1,0 +1,175 @@
+"""Pins the oracle restatement (oracle/mrt_oracle.c) to the REFERENCE: the golden
+vectors in tests/golden/ were produced by the reference's own TinyBVH 1.6.7
+(oracle/_ref, built from /root/reference) with tests/golden/make_golden.py.
+The reference ships no tests of its own, so these are the pins.
+CPU only."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+from messyerraytracer_amd import synth
+from oracle import pyoracle as po
+import parity
+
+
+def _load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def _check_vs_ref(osc, rays, hits_ref, any_ref, what):
+    got = osc.trace(rays)
+    st = parity.assert_reference_parity(got["prim_id"], got["t"], hits_ref["prim_id"], hits_ref["t"], rays, osc.tris, what)
+    # any-hit must agree with nearest-hit of the same implementation, and with the reference's
+    # occlusion flags except on explained edge cases
+    any_o = osc.trace(rays, any_hit=True)["prim_id"] >= 0
+    assert np.array_equal(any_o, got["prim_id"] >= 0)
+    bad = np.nonzero(any_o != any_ref)[0]
+    for i in bad:
+        p = int(got["prim_id"][i]) if any_o[i] else int(hits_ref["prim_id"][i])
+        assert parity.explain_mismatch(osc.tris, rays[i], p, -1), f"{what}: any-hit disagrees on ray {i}"
+    return st
+
+
+def test_g1_cube_config1():
+    """Config C1: 12-tri cube, 16x12 grid of cast_debug_rays (raytracer_debug.cpp:572-596)."""
+    g = _load("g1_cube.npz")
+    osc = po.OracleScene(synth.cube())
+    c1 = synth.CONFIGS["C1"]
+    rays = po.grid_rays(c1["origin"], c1["forward"], *c1["grid"], c1["fov"])
+    assert rays.tobytes() == g["rays"].tobytes()
+    assert rays.shape[0] == 192
+    _check_vs_ref(osc, rays, g["hits_ref"], g["any_ref"], "G1")
+    assert 0 < (g["hits_ref"]["prim_id"] >= 0).sum() < 192
+    # normals of a unit cube are axis aligned, +z face seen from z=3
+    got = osc.trace(rays)
+    hit = got["prim_id"] >= 0
+    assert np.allclose(got["normal"][hit], [0, 0, 1])
+    assert np.allclose(got["t"][hit] * rays["direction"][hit][:, 2], -2.5, rtol=1e-6)
+
+
+@pytest.mark.parametrize("key", ["hits_ref", "hits_ref_bvh4", "hits_ref_bvh2"])
+def test_g2_soup_grid(key):
+    g = _load("g2_soup1k_grid.npz")
+    osc = po.OracleScene(synth.soup(1000, 0.5, 1))
+    rays = po.grid_rays((0, 0, -12), (0, 0, 1), 64, 64, 50.0)
+    assert rays.tobytes() == g["rays"].tobytes()
+    _check_vs_ref(osc, rays, g[key], g["any_ref"], "G2/" + key)
+
+
+def test_g3_soup_incoherent():
+    g = _load("g3_soup1k_incoherent.npz")
+    osc = po.OracleScene(synth.soup(1000, 0.5, 1))
+    rays = synth.incoherent_rays(4096, seed=2)
+    assert rays.tobytes() == g["rays"].tobytes(), "synthetic ray generator is not machine independent"
+    _check_vs_ref(osc, rays, g["hits_ref"], g["any_ref"], "G3")
+
+
+def test_g4_bvh_builder_matches_tinybvh():
+    """8-bin SAH builder restatement vs tinybvh::BVH::Build: invariants at every size,
+    bit-identical node / primIdx arrays where the reference builds single-threaded."""
+    with open(os.path.join(GOLDEN, "g4_bvh_invariants.json")) as f:
+        inv = json.load(f)
+    for n_str, want in inv.items():
+        n = int(n_str)
+        s = {12: None, 1000: 0.5, 10000: 0.2, 100000: 0.10}[n]
+        v = synth.cube() if s is None else synth.soup(n, s, 1)
+        nodes, prim_idx, used = po.bvh2_build(po.verts4(v))
+        info = po.bvh2_info(nodes)
+        assert used == want["used_nodes"]
+        assert info["node_count"] == want["node_count"] == used - 1  # node 1 is a hole
+        assert info["leaf_count"] == want["leaf_count"]
+        assert info["sah_cost"] == pytest.approx(want["sah_cost"], rel=1e-6)
+        assert sorted(prim_idx.tolist()) == list(range(n))
+        if "nodes_sha256" in want:
+            assert hashlib.sha256(nodes.tobytes()).hexdigest() == want["nodes_sha256"]
+            assert hashlib.sha256(prim_idx.tobytes()).hexdigest() == want["prim_idx_sha256"]
+
+
+def test_c2_sampled_vs_reference():
+    """Config C2 (100 k tris, 1024^2): 16384 sampled rays of the reference's result."""
+    g = _load("c2_sampled.npz")
+    cfg = synth.CONFIGS["C2"]
+    osc = po.OracleScene(synth.scene_vertices(cfg))
+    rays = po.grid_rays(cfg["origin"], cfg["forward"], *cfg["grid"], cfg["fov"])[g["index"]]
+    got = osc.trace(rays)
+    parity.assert_reference_parity(got["prim_id"], got["t"], g["prim_id"], g["t"], rays, osc.tris, "C2")
+    info = json.loads(str(g["bvh"]))
+    mine = po.bvh2_info(osc.nodes)
+    assert mine["node_count"] == info["node_count"] and mine["leaf_count"] == info["leaf_count"]
+
+
+def test_bvh_equals_brute_force():
+    """ray_scene.h:93-131: BVH traversal and the brute-force loop agree exactly."""
+    for seed, n, s in [(5, 300, 0.8), (6, 3000, 0.3)]:
+        osc = po.OracleScene(synth.soup(n, s, seed))
+        rays = np.concatenate([po.grid_rays((0, 0, -12), (0, 0, 1), 48, 48, 50.0), synth.incoherent_rays(2048, seed)])
+        a, b = osc.trace(rays), osc.brute(rays)
+        assert a.tobytes() == b.tobytes()
+        assert np.array_equal(osc.trace(rays, any_hit=True)["prim_id"] >= 0, b["prim_id"] >= 0)
+
+
+def test_query_mask_and_degenerate_rays():
+    v = synth.soup(500, 0.8, 9)
+    layers = np.where(np.arange(500) % 2 == 0, 1, 2).astype(np.uint32)
+    osc = po.OracleScene(v, layers=layers)
+    rays = po.grid_rays((0, 0, -12), (0, 0, 1), 32, 32, 50.0)
+    for mask in (1, 2, 3, 0):
+        h = osc.trace(rays, query_mask=mask)
+        assert h.tobytes() == osc.brute(rays, query_mask=mask).tobytes()
+        hit = h["prim_id"] >= 0
+        assert ((h["hit_layers"][hit] & mask) != 0).all()
+        if mask == 0:
+            assert not hit.any()
+    rays2 = rays.copy()
+    rays2["t_min"] = 5.0
+    rays2["t_max"] = 5.0  # t_min >= t_max: miss with t = t_max (bvh_traverse.comp.glsl:214-222)
+    h = osc.trace(rays2)
+    assert (h["prim_id"] == -1).all() and (h["t"] == 5.0).all()
+
+
+def test_morton_key_properties():
+    """ray_sort.h:41-76: 30-bit key, 10 bits per axis, x most significant."""
+    assert po.morton_keys(np.zeros(0, dtype=po.RAY32)).shape == (0,)
+    r = np.zeros(4, dtype=po.RAY32)
+    r["direction"] = [[-1, -1, -1], [1, 1, 1], [1, -1, -1], [-1, -1, 1]]
+    k = po.morton_keys(r)
+    assert k[0] == 0 and k[1] == (1 << 30) - 1
+    assert k[2] == 0x24924924 and k[3] == 0x09249249
+    rays = synth.incoherent_rays(10000, 3)
+    keys = po.morton_keys(rays)
+    assert keys.max() < (1 << 30)
+    q = np.floor(np.clip((rays["direction"] + np.float32(1)) * np.float32(0.5), 0, 1) * np.float32(1023)).astype(np.uint32)
+    for bit in range(10):  # de-interleave and compare with the quantised coordinates
+        assert np.array_equal((keys >> (3 * bit + 2)) & 1, (q[:, 0] >> bit) & 1)
+        assert np.array_equal((keys >> (3 * bit + 1)) & 1, (q[:, 1] >> bit) & 1)
+        assert np.array_equal((keys >> (3 * bit)) & 1, (q[:, 2] >> bit) & 1)
+
+
+def test_host_conversions_roundtrip():
+    """Ray <-> GPURayPacked and GPUIntersectionPacked -> Intersection (gpu_ray_caster.cpp:639-650,442-456)."""
+    osc = po.OracleScene(synth.soup(200, 0.9, 4))
+    rays = po.grid_rays((0, 0, -12), (0, 0, 1), 16, 16, 50.0)
+    host = po.make_host_rays(rays)
+    assert po.pack_rays(host).tobytes() == rays.tobytes()
+    assert np.array_equal(host["dir_sign"], (rays["direction"] < 0).astype(np.int32))
+    hits = osc.trace(rays)
+    out = po.unpack_hits(hits, host)
+    hit = hits["prim_id"] >= 0
+    assert hit.any() and (~hit).any()
+    assert np.array_equal(out["prim_id"][hit], hits["prim_id"][hit].astype(np.uint32))
+    assert (out["prim_id"][~hit] == 0xFFFFFFFF).all() and (out["t"][~hit] == np.float32(3.4028234663852886e38)).all()
+    pos = rays["origin"][hit] + rays["direction"][hit] * hits["t"][hit][:, None]
+    assert np.array_equal(out["position"][hit], pos.astype(np.float32))
+
+
+@pytest.mark.skipif(not po.ref_available(), reason="oracle/_ref not built (needs /root/reference)")
+def test_live_reference_agrees_with_fixtures():
+    """Where the reference library is present, re-run it and compare with the committed vectors."""
+    g = _load("g2_soup1k_grid.npz")
+    rs = po.RefScene(synth.soup(1000, 0.5, 1), variants=7)
+    assert rs.cast_rays(g["rays"], variant=8).tobytes() == g["hits_ref"].tobytes()
+    assert rs.cast_rays(g["rays"], variant=2).tobytes() == g["hits_ref_bvh2"].tobytes()
