@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""bench.py — Mrays/s (primary, closest-hit) on BASELINE.json's headline config.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch: mrt_cast over the 4096x4096
+primary-ray grid (config C3: 1 M-triangle soup, 8-bin SAH BVH2), rays already
+resident in HBM in row-major order, 32-byte hit records written to HBM.  At N > 1
+every rank traces its own full grid (one view per GPU, BVH replicated: weak
+scaling) and the hit records are gathered on rank 0 over RCCL inside the timed
+region, chunked so the copy overlaps the tracing.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), including
+  roofline     algorithmic bytes / measured kernel time vs the 8 TB/s HBM peak
+  cpu_baseline the reference's own CPU path (TinyBVH BVH8 under a range-split
+               thread pool, oracle/_ref) on this box's host cores, N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md "Chip-level parameters"
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="C3", help="C2 | C3 (headline) | C5")
+    ap.add_argument("--mode", default="cast", choices=["cast", "tiled", "fused"],
+                    help="cast: mrt_cast on row-major device rays (headline); tiled: mrt_cast_tiled; fused: mrt_cast_grid")
+    ap.add_argument("--chunks", type=int, default=4, help="row chunks per step at N > 1 (gather/trace overlap)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--grid-tile", type=int, default=0)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, verts):
+    """The reference CPU path timed on this box's host cores (bounded: one pass over the
+    same 4096^2 grid after a warm-up pass over 1/8 of it).  Checker code, used here only
+    as the reported baseline."""
+    from oracle import pyoracle as po
+    cores = len(os.sched_getaffinity(0))
+    w, h = cfg["grid"]
+    rays = po.grid_rays(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
+    if po.ref_available():
+        rs = po.RefScene(verts)
+        rs.cast_rays(rays[: rays.shape[0] // 8], n_threads=cores)
+        t0 = time.perf_counter()
+        rs.cast_rays(rays, n_threads=cores)
+        dt = time.perf_counter() - t0
+        kind = "reference"
+        what = "tinybvh::BVH8_CPU::Intersect (AVX2) under the ThreadPool range split" if po.ref().ref_has_avx2() else \
+            "tinybvh::BVH4_CPU::Intersect (SSE) under the ThreadPool range split"
+        rs.close()
+    else:
+        osc = po.OracleScene(verts)
+        osc.trace(rays[: rays.shape[0] // 8], n_threads=cores)
+        t0 = time.perf_counter()
+        osc.trace(rays, n_threads=cores)
+        dt = time.perf_counter() - t0
+        kind, what = "port", "oracle/mrt_oracle.c scalar BVH2 walk, OpenMP"
+    return dict(value=rays.shape[0] / dt / 1e6, unit="Mrays/s", cores=cores, kind=kind,
+                sample=f"one pass over the full {w}x{h} grid of the same scene ({what}; BVH build excluded)")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    from messyerraytracer_amd import capi, synth, sharded
+    cfg = synth.CONFIGS[a.config]
+    w, h = cfg["grid"]
+    verts = synth.scene_vertices(cfg)
+    scene = capi.Scene(verts)
+    ctx = capi.Context(local_rank, grid_tile=a.grid_tile)
+    stream = torch.cuda.current_stream(device)
+    ctx.set_stream(stream.cuda_stream)
+    scene.upload(ctx)
+
+    # one view per rank: the camera orbits the scene centre (rank 0 = the config's own camera)
+    ang = 2.0 * np.pi * rank / max(world, 1)
+    o = np.array(cfg["origin"], dtype=np.float64)
+    f = np.array(cfg["forward"], dtype=np.float64)
+    rot = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
+    cam = capi.camera_look(tuple((rot @ o).astype(np.float32)), tuple((rot @ f).astype(np.float32)), w, h, cfg["fov"])
+
+    n_rays = w * h
+    d_rays = torch.empty(n_rays * 32, dtype=torch.uint8, device=device)
+    ctx.generate_grid(cam, w, h, 0, h, d_rays)          # untimed: inputs resident in HBM
+    trace_ms = []
+    dev_flags = capi.FLAG_COHERENT | capi.FLAG_RAYS_ON_DEVICE | capi.FLAG_HITS_ON_DEVICE
+
+    def tracer(y0, y1, out):
+        if a.mode == "fused":
+            ctx.cast_grid(cam, w, h, y0=y0, y1=y1, hits=out, flags=capi.FLAG_HITS_ON_DEVICE)
+        elif a.mode == "tiled":
+            ctx.cast_tiled(d_rays.data_ptr() + y0 * w * 32, out, w, y1 - y0)
+        else:
+            ctx.cast(d_rays.data_ptr() + y0 * w * 32, out, count=(y1 - y0) * w, flags=dev_flags)
+        trace_ms.append(ctx.stats()["last_trace_ms"])
+
+    chunks = a.chunks if world > 1 else 1
+    job = sharded.ShardedViews(w, h, tracer, device, chunks=chunks, gather=not a.no_gather)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(device)
+
+    for _ in range(a.warmup):
+        job.step()
+    sync()
+    trace_ms.clear()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        job.step()
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        total_rays = n_rays * world * a.steps
+        out = {
+            "metric": "Mrays/s (primary, closest-hit)", "value": total_rays / dt / 1e6, "unit": "Mrays/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{a.config}: {verts.shape[0]}-triangle soup (seed {cfg.get('seed')}), 8-bin SAH BVH2, "
+                                   f"{w}x{h} primary-ray grid per GPU, closest hit, rays+hits HBM-resident",
+                       "entry": {"cast": "mrt_cast(COHERENT)", "tiled": "mrt_cast_tiled", "fused": "mrt_cast_grid"}[a.mode],
+                       "views": world, "gather": "rccl gather to rank 0, %d chunks" % chunks if world > 1 and not a.no_gather else "none"},
+        }
+        # roofline of the dominant kernel (trace_lane_kernel): algorithmic bytes / kernel time
+        stats_path = os.path.join(ROOT, "tests", "golden", "traversal_stats.json")
+        kernel_ms = float(np.sum(trace_ms)) / a.steps          # per step (all chunks), rank 0
+        roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+                "kernel": "trace_lane_kernel<false,false>", "kernel_ms": kernel_ms}
+        if os.path.exists(stats_path):
+            st = json.load(open(stats_path)).get(a.config)
+            if st:
+                bytes_per_launch = st["bytes_per_ray"] * n_rays
+                roof.update(achieved=bytes_per_launch / (kernel_ms * 1e-3) / 1e9, bytes_per_ray=st["bytes_per_ray"],
+                            n_int=st["n_int"], n_tri=st["n_tri"])
+                roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            roof["traffic"] = json.load(open(pmc)).get(a.config, {}).get("hbm_bytes_per_launch")
+        out["roofline"] = roof
+        out["kernel_only_mrays"] = n_rays / (kernel_ms * 1e-3) / 1e6
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, verts)
+        print(json.dumps(out), flush=True)
+    ctx.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

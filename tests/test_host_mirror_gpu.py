@@ -1,0 +1,58 @@
+"""The C++ GPURayCaster / RayDispatcher mirrors (messyerraytracer_amd/csrc/host/*.hpp),
+driven the way the reference's callers drive theirs, against the oracle."""
+import os
+import struct
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+from messyerraytracer_amd import build as mbuild, synth, types as T
+from oracle import pyoracle as po
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("scene", ["cube", "soup"])
+def test_ray_dispatcher_mirror(built, scene):
+    exe = mbuild.build_host_test()
+    if scene == "cube":
+        v = synth.cube()
+        c1 = synth.CONFIGS["C1"]
+        rays = po.grid_rays(c1["origin"], c1["forward"], *c1["grid"], c1["fov"])  # 192 rays: < 256, never sorted
+    else:
+        v = synth.soup(3000, 0.4, 12)
+        rays = np.concatenate([po.grid_rays((0, 0, -12), (0, 0, 1), 64, 48, 50.0), synth.incoherent_rays(2000, 9)])
+    host = po.make_host_rays(rays)
+    n = rays.shape[0]
+    with tempfile.TemporaryDirectory() as d:
+        fin, fout = os.path.join(d, "in.bin"), os.path.join(d, "out.bin")
+        with open(fin, "wb") as f:
+            f.write(struct.pack("<I", v.shape[0]))
+            f.write(np.ascontiguousarray(v, dtype=np.float32).tobytes())
+            f.write(struct.pack("<I", n))
+            f.write(host.tobytes())
+        r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert "CPU backend" in r.stderr  # Backend::CPU failed loudly instead of falling back
+        raw = open(fout, "rb").read()
+    header = np.frombuffer(raw[:32], dtype=np.int32)
+    off = 32
+    coherent = np.frombuffer(raw[off:off + 44 * n], dtype=T.HOST_HIT44); off += 44 * n
+    sorted_ = np.frombuffer(raw[off:off + 44 * n], dtype=T.HOST_HIT44); off += 44 * n
+    any_hit = np.frombuffer(raw[off:off + n], dtype=np.uint8).astype(bool); off += n
+    async_ = np.frombuffer(raw[off:off + 44 * n], dtype=T.HOST_HIT44); off += 44 * n
+    single = np.frombuffer(raw[off:off + 44], dtype=T.HOST_HIT44)
+    assert header[0] == 8            # MRT_ERR_UNSUPPORTED for the CPU backend
+    assert header[1] == 1 and header[2] == v.shape[0]
+    assert header[5] == 0 and header[6] == 0 and header[7] == 0
+    osc = po.OracleScene(v)
+    assert header[3] == osc.used_nodes - 1
+    want = po.unpack_hits(osc.trace(rays), host)
+    assert coherent.tobytes() == want.tobytes()
+    assert sorted_.tobytes() == want.tobytes()
+    assert async_.tobytes() == want.tobytes()
+    assert np.array_equal(any_hit, want["prim_id"] != 0xFFFFFFFF)
+    assert single.tobytes() == want[:1].tobytes()
