@@ -135,6 +135,9 @@ typedef struct mrt_stats {
 	float last_h2d_ms, last_d2h_ms;
 	uint32_t last_kernel_launches;
 	uint32_t max_stack_depth;    /* count_visits only                           */
+	uint64_t dead_pops;          /* count_visits, packet kernel: popped nodes no lane still needed */
+	uint32_t detected_grid_w;    /* count_visits: row width found for the last coherent mrt_cast (0 = none) */
+	uint32_t reserved;
 } mrt_stats;
 
 /* mode: RayQuery::Mode, src/api/ray_query.h:54-57 / RAY_MODE spec constant,
@@ -165,7 +168,12 @@ typedef struct mrt_options {
 	uint32_t count_visits;    /* 1: counting kernel variant fills mrt_stats counters  */
 	uint32_t sort_threshold;  /* MIN_BATCH_FOR_SORTING, default 256 (ray_dispatcher.h:427) */
 	uint32_t grid_tile;       /* 0: default 8x8 lane tiling for grid casts; 1: row-major */
-	uint32_t reserved[11];
+	/* tuning knobs (0 = default); results never depend on them */
+	uint32_t tile_w_log2;     /* lane tile is 2^k wide, 64/2^k high (default k = 3: 8x8)            */
+	uint32_t xcd_swizzle;     /* 1: give each XCD a contiguous band of the batch (default: the hardware's
+	                             round-robin placement, which balances cheap and expensive image regions) */
+	uint32_t stack_override;  /* LDS stack entries per lane (lane kernel), >= what the BVH needs    */
+	uint32_t reserved[8];
 } mrt_options;
 
 typedef struct mrt_ctx mrt_ctx;

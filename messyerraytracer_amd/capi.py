@@ -38,7 +38,8 @@ class MrtError(RuntimeError):
 
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("kernel", C.c_uint32), ("count_visits", C.c_uint32),
-                ("sort_threshold", C.c_uint32), ("grid_tile", C.c_uint32), ("reserved", C.c_uint32 * 11)]
+                ("sort_threshold", C.c_uint32), ("grid_tile", C.c_uint32), ("tile_w_log2", C.c_uint32),
+                ("xcd_swizzle", C.c_uint32), ("stack_override", C.c_uint32), ("reserved", C.c_uint32 * 8)]
 
 
 class Camera(C.Structure):
@@ -50,7 +51,7 @@ class Stats(C.Structure):
     _fields_ = [("rays_cast", C.c_uint64), ("tri_tests", C.c_uint64), ("bvh_nodes_visited", C.c_uint64),
                 ("hits", C.c_uint64), ("last_trace_ms", C.c_float), ("last_sort_ms", C.c_float),
                 ("last_h2d_ms", C.c_float), ("last_d2h_ms", C.c_float), ("last_kernel_launches", C.c_uint32),
-                ("max_stack_depth", C.c_uint32)]
+                ("max_stack_depth", C.c_uint32), ("dead_pops", C.c_uint64), ("detected_grid_w", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 _lib = None
@@ -153,7 +154,8 @@ class Context:
     """mrt_ctx wrapper: one per GPU, externally serialised (SURVEY 8(b) threading)."""
 
     def __init__(self, device: int = 0, kernel: int = KERNEL_AUTO, count_visits: bool = False,
-                 sort_threshold: int = 0, grid_tile: int = 0):
+                 sort_threshold: int = 0, grid_tile: int = 0, tile_w_log2: int = 0, xcd_swizzle: int = 0,
+                 stack_override: int = 0):
         self.L = load()
         opts = Options()
         opts.struct_size = C.sizeof(Options)
@@ -161,6 +163,9 @@ class Context:
         opts.count_visits = 1 if count_visits else 0
         opts.sort_threshold = sort_threshold
         opts.grid_tile = grid_tile
+        opts.tile_w_log2 = tile_w_log2
+        opts.xcd_swizzle = xcd_swizzle
+        opts.stack_override = stack_override
         self.h = C.c_void_p()
         rc = self.L.mrt_create(device, C.byref(opts), C.byref(self.h))
         if rc:

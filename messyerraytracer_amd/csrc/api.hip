@@ -20,6 +20,8 @@ namespace mrt {
 hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream);
 hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t stream);
 hipError_t launch_morton_keys(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t *keys, uint32_t *index, hipStream_t stream);
+hipError_t launch_detect_grid(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t tile_w_log2,
+		unsigned long long *scratch, uint32_t *out, hipStream_t stream);
 }
 
 struct DevBuf {
@@ -101,8 +103,19 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 	std::memset(&p, 0, sizeof(p));
 	p.nodes = ctx->d_nodes; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold;
 	p.stack_depth = ctx->stack_depth;
+	if (ctx->opts.stack_override >= ctx->depth && ctx->opts.stack_override <= 64) p.stack_depth = ctx->opts.stack_override;
 	p.counters = ctx->d_counters;
-	p.xcd_swizzle = 1;
+	p.xcd_swizzle = ctx->opts.xcd_swizzle ? 1 : 0;
+	p.tile_w_log2 = (ctx->opts.tile_w_log2 >= 1 && ctx->opts.tile_w_log2 <= 6) ? ctx->opts.tile_w_log2 : 3;
+	p.kernel = MRT_KERNEL_LANE; // callers pick per batch with pick_kernel()
+}
+
+// MRT_KERNEL_AUTO: packets for batches the caller declares coherent (RayQuery::coherent,
+// primary-ray grids), one lane per ray for everything else (sorted / incoherent batches).
+uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent)
+{
+	if (ctx->opts.kernel == MRT_KERNEL_LANE || ctx->opts.kernel == MRT_KERNEL_PACKET) return ctx->opts.kernel;
+	return coherent ? MRT_KERNEL_PACKET : MRT_KERNEL_LANE;
 }
 
 int drain_pending(mrt_ctx *ctx)
@@ -161,16 +174,25 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	const uint32_t thr = ctx->opts.sort_threshold ? ctx->opts.sort_threshold : 256u; // MIN_BATCH_FOR_SORTING
 	const bool sort = !(flags & MRT_FLAG_COHERENT) && (count >= thr || (flags & MRT_FLAG_FORCE_SORT));
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
+	p.kernel = pick_kernel(ctx, !sort && (flags & MRT_FLAG_COHERENT));
 	if (sort) {
 		const uint32_t *perm = nullptr;
 		if ((rc = device_sort(ctx, d_rays, p.in_fmt, count, &perm))) return rc;
 		p.perm = perm;
 	}
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+	// Coherent batch without a declared width: look for the row width on the device and let the
+	// trace kernel tile its lanes (no host round trip: the kernel reads the answer from HBM).
+	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 4096 && ctx->opts.grid_tile != 1;
+	if (detect) {
+		uint32_t *d_auto = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);
+		HIP_TRY(ctx, mrt::launch_detect_grid(d_rays, p.in_fmt, count, p.tile_w_log2, ctx->d_counters + 16, d_auto, ctx->stream));
+		p.lane_map = mrt::MAP_AUTO; p.auto_grid = d_auto;
+	}
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-	ctx->stats.last_kernel_launches = sort ? 3 : 1;
+	ctx->stats.last_kernel_launches = sort ? 3 : (detect ? 2 : 1);
 	ctx->stats.rays_cast += count;
 	*d_hits_out = d_hits;
 	return MRT_OK;
@@ -188,6 +210,10 @@ int finish_timing(mrt_ctx *ctx, bool h2d, bool sorted, bool d2h)
 		HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
 		ctx->stats.tri_tests += c[1]; ctx->stats.bvh_nodes_visited += c[2]; ctx->stats.hits += c[3];
 		if ((uint32_t)c[4] > ctx->stats.max_stack_depth) ctx->stats.max_stack_depth = (uint32_t)c[4];
+		ctx->stats.dead_pops += c[5];
+		uint32_t g[4] = {0, 0, 0, 0};
+		if (ctx->stats.last_kernel_launches == 2) HIP_TRY(ctx, hipMemcpy(g, ctx->d_counters + 8, sizeof(g), hipMemcpyDeviceToHost));
+		ctx->stats.detected_grid_w = g[0];
 	}
 	return MRT_OK;
 }
@@ -234,7 +260,9 @@ int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
 	if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(MRT_ERR_HIP);
 	ctx->stream = ctx->own_stream;
 	for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) return bail(MRT_ERR_HIP);
-	if (hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_OOM);
+	// [0..7] visit counters, [8..15] detected grid, [16..1040] detect_grid_kernel scratch (masks + ticket)
+	if (hipMalloc(&ctx->d_counters, (16 + 1025) * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_OOM);
+	if (hipMemset(ctx->d_counters, 0, (16 + 1025) * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_HIP);
 	*out = ctx;
 	return MRT_OK;
 }
@@ -372,7 +400,7 @@ static int grid_params(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uin
 	if (!cam || grid_w == 0 || grid_h == 0 || y0 > y1 || y1 > grid_h) return fail(ctx, MRT_ERR_INVALID, "bad grid");
 	base_params(ctx, p);
 	p.cam = *cam; p.grid_w = grid_w; p.grid_h = grid_h; p.y0 = y0; p.rows = y1 - y0;
-	p.tiles_x = (grid_w + 7u) / 8u;
+	p.tiles_x = (grid_w + (1u << p.tile_w_log2) - 1u) >> p.tile_w_log2;
 	p.count = (uint64_t)grid_w * (y1 - y0);
 	p.in_fmt = mrt::IN_GRID;
 	return MRT_OK;
@@ -410,6 +438,7 @@ int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t
 	p.hits = d_hits; p.query_mask = query_mask;
 	p.out_fmt = hs == 1 ? mrt::OUT_BOOL8 : mrt::OUT_HIT32;
 	p.lane_map = ctx->opts.grid_tile == 1 ? mrt::MAP_LINEAR : mrt::MAP_TILE8X8;
+	p.kernel = pick_kernel(ctx, true);
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
@@ -437,7 +466,9 @@ int mrt_cast_tiled(mrt_ctx *ctx, const mrt_ray32 *d_rays, mrt_hit32 *d_hits,
 	p.rays = d_rays; p.hits = d_hits; p.count = (uint64_t)grid_w * rows; p.query_mask = query_mask;
 	p.in_fmt = mrt::IN_RAY32; p.out_fmt = mrt::OUT_HIT32;
 	p.lane_map = ctx->opts.grid_tile == 1 ? mrt::MAP_LINEAR : mrt::MAP_TILE8X8;
-	p.grid_w = grid_w; p.grid_h = rows; p.y0 = 0; p.rows = rows; p.tiles_x = (grid_w + 7u) / 8u;
+	p.kernel = pick_kernel(ctx, true);
+	p.grid_w = grid_w; p.grid_h = rows; p.y0 = 0; p.rows = rows;
+	p.tiles_x = (grid_w + (1u << p.tile_w_log2) - 1u) >> p.tile_w_log2;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));

@@ -42,14 +42,21 @@ struct RayRegs {
 __device__ __forceinline__ bool lane_ray_index(const TraceParams &p, uint32_t block, uint64_t &ray_idx, uint32_t &px, uint32_t &py)
 {
 	const uint64_t g = (uint64_t)block * MRT_WG + threadIdx.x;
-	if (p.lane_map == MAP_TILE8X8) {
+	uint32_t lane_map = p.lane_map, grid_w = p.grid_w, rows = p.rows, tiles_x = p.tiles_x;
+	if (lane_map == MAP_AUTO) { // row width found on the device by detect_grid_kernel (0 = not a grid)
+		const uint32_t w = p.auto_grid[0];
+		lane_map = w ? MAP_TILE8X8 : MAP_LINEAR;
+		grid_w = w; rows = p.auto_grid[1]; tiles_x = p.auto_grid[2];
+	}
+	if (lane_map == MAP_TILE8X8) {
 		const uint64_t tile = g >> 6;
 		const uint32_t l = (uint32_t)g & 63u;
-		const uint32_t tx = (uint32_t)(tile % p.tiles_x), ty = (uint32_t)(tile / p.tiles_x);
-		px = tx * 8u + (l & 7u);
-		py = ty * 8u + (l >> 3);
-		if (px >= p.grid_w || py >= p.rows) return false;
-		ray_idx = (uint64_t)py * p.grid_w + px;
+		const uint32_t tx = (uint32_t)(tile % tiles_x), ty = (uint32_t)(tile / tiles_x);
+		const uint32_t k = p.tile_w_log2; // tile is 2^k wide, 64 / 2^k high
+		px = (tx << k) + (l & ((1u << k) - 1u));
+		py = (ty << (6u - k)) + (l >> k);
+		if (px >= grid_w || py >= rows) return false;
+		ray_idx = (uint64_t)py * grid_w + px;
 		return true;
 	}
 	if (g >= p.count) return false;
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 	load_ray(p, ray_idx, px, py, r);
 
 	float best_t = r.t_max, best_u = 0.0f, best_v = 0.0f;
-	uint32_t best_slot = 0xFFFFFFFFu;
+	uint32_t best_slot = 0xFFFFFFFFu, best_id = 0xFFFFFFFFu;
 	uint32_t n_nodes = 0, n_tris = 0, max_sp = 0;
 
 	if (!(r.t_min >= r.t_max)) { // degenerate rays are misses, glsl:214-222
@@ -206,8 +213,11 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 								const float v = dot3(r.dx, r.dy, r.dz, qvx, qvy, qvz) * inv_det;
 								if (!(v < 0.0f || u + v > 1.0f)) {
 									const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
-									if (!(t < r.t_min || t >= best_t)) {
-										best_t = t; best_u = u; best_v = v; best_slot = slot;
+									// glsl:124 accepts t_min <= t < best_t; an exact tie goes to the lower
+									// triangle id so the answer does not depend on the visiting order
+									const uint32_t id = __float_as_uint(q0.w);
+									if (!(t < r.t_min) && (t < best_t || (t == best_t && best_slot != 0xFFFFFFFFu && id < best_id))) {
+										best_t = t; best_u = u; best_v = v; best_slot = slot; best_id = id;
 										if (ANY_HIT) last = true;
 									}
 								}
@@ -241,6 +251,8 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 	}
 }
 
+#include "packet_kernel.h"
+
 // ---- standalone ray generation (mrt_generate_grid) ---------------------------------
 __global__ __launch_bounds__(MRT_WG) void grid_rays_kernel(const TraceParams p, mrt_ray32 *out)
 {
@@ -253,6 +265,94 @@ __global__ __launch_bounds__(MRT_WG) void grid_rays_kernel(const TraceParams p, 
 	a.x = r.ox; a.y = r.oy; a.z = r.oz; a.w = r.t_max;
 	b.x = r.dx; b.y = r.dy; b.z = r.dz; b.w = r.t_min;
 	q[0] = a; q[1] = b;
+}
+
+// ---- row-width detection for coherent batches ------------------------------------------
+// RayQuery::coherent (src/api/ray_query.h:69-76) says "these are primary camera rays" but
+// the reference's cast_rays(rays, results, count) carries no image width, and a wave of 64
+// consecutive rays is a 64x1 pixel strip.  One small block looks at the first rows: inside
+// a row consecutive directions differ by one pixel step, at a row end they jump back by a
+// whole row.  If the first two jumps sit at w and 2w and w x rows tiles the batch exactly,
+// the trace kernel maps its lanes to 2^k x 64/2^k pixel tiles instead.  Purely a speed
+// decision: any lane -> ray mapping gives the same results.
+#define MRT_DETECT_THREADS 1024
+#define MRT_DETECT_MAX_RAYS 65536u
+// scratch layout (uint64 words): [0 .. 1023] jump bit masks, [1024] finished-block ticket
+__device__ __forceinline__ void ray_dir(const void *rays, uint32_t in_fmt, uint64_t i, float &x, float &y, float &z)
+{
+	if (in_fmt == IN_HOST60) {
+		const float *h = reinterpret_cast<const float *>(rays) + i * 15u;
+		x = h[3]; y = h[4]; z = h[5];
+	} else {
+		const float4 b = reinterpret_cast<const float4 *>(rays)[i * 2u + 1u];
+		x = b.x; y = b.y; z = b.z;
+	}
+}
+__global__ __launch_bounds__(MRT_DETECT_THREADS) void detect_grid_kernel(const void *rays, uint32_t in_fmt, uint64_t count,
+		uint32_t tile_w_log2, unsigned long long *scratch, uint32_t *out)
+{
+	__shared__ uint32_t first, second, is_last;
+	const uint32_t m = (uint32_t)(count < (uint64_t)MRT_DETECT_MAX_RAYS ? count : (uint64_t)MRT_DETECT_MAX_RAYS);
+	float ax, ay, az, bx, by, bz;
+	ray_dir(rays, in_fmt, 0, ax, ay, az);
+	ray_dir(rays, in_fmt, 1, bx, by, bz);
+	const float step2 = (bx - ax) * (bx - ax) + (by - ay) * (by - ay) + (bz - az) * (bz - az);
+	const float thr = 36.0f * step2; // a jump of more than 6 pixel steps
+	// phase 1: every thread looks at one pair (i-1, i); one 64-bit jump mask per wave
+	const uint32_t i = blockIdx.x * MRT_DETECT_THREADS + threadIdx.x;
+	bool jump = false;
+	if (i >= 1 && i < m) {
+		ray_dir(rays, in_fmt, i - 1, ax, ay, az);
+		ray_dir(rays, in_fmt, i, bx, by, bz);
+		jump = (bx - ax) * (bx - ax) + (by - ay) * (by - ay) + (bz - az) * (bz - az) > thr;
+	}
+	const unsigned long long mask = __ballot(jump);
+	if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(&scratch[i >> 6], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	// hand-off to the block that finishes last (agent-scope release / acquire, guide G16)
+	__threadfence();
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		const unsigned long long t = atomicAdd(&scratch[1024], 1ull);
+		is_last = (t == (unsigned long long)gridDim.x - 1ull) ? 1u : 0u;
+		first = 0xFFFFFFFFu; second = 0xFFFFFFFFu;
+	}
+	__syncthreads();
+	if (!is_last) return;
+	__threadfence();
+	// phase 2 (one block): first and second jump over the <= 1024 mask words
+	const uint32_t words = (m + 63u) >> 6;
+	unsigned long long wmask = 0ull;
+	if (threadIdx.x < words) wmask = __hip_atomic_load(&scratch[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	if (wmask) atomicMin(&first, threadIdx.x * 64u + (uint32_t)__builtin_ctzll(wmask));
+	__syncthreads();
+	const uint32_t f = first;
+	if (f != 0xFFFFFFFFu && threadIdx.x >= (f >> 6)) {
+		unsigned long long rest = wmask;
+		if (threadIdx.x == (f >> 6)) rest &= ~((2ull << (f & 63u)) - 1ull); // clear bits <= f
+		if (rest) atomicMin(&second, threadIdx.x * 64u + (uint32_t)__builtin_ctzll(rest));
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		uint32_t w = first, rows = 0, tiles_x = 0;
+		const uint32_t tw = 1u << tile_w_log2, th = 64u >> tile_w_log2;
+		bool ok = step2 > 0.0f && w != 0xFFFFFFFFu && w >= 16u && (w % tw) == 0u && (count % w) == 0ull;
+		if (ok) {
+			const uint64_t r = count / w;
+			ok = r <= 0xFFFFFFFFull && (r % th) == 0ull && (2ull * w >= m || second == 2u * w);
+			rows = (uint32_t)r; tiles_x = w >> tile_w_log2;
+		}
+		out[0] = ok ? w : 0u; out[1] = ok ? rows : 0u; out[2] = ok ? tiles_x : 0u;
+		scratch[1024] = 0ull; // ticket for the next launch (stream ordered)
+	}
+}
+
+hipError_t launch_detect_grid(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t tile_w_log2,
+		unsigned long long *scratch, uint32_t *out, hipStream_t stream)
+{
+	const uint32_t m = (uint32_t)(count < (uint64_t)MRT_DETECT_MAX_RAYS ? count : (uint64_t)MRT_DETECT_MAX_RAYS);
+	const uint32_t blocks = (m + MRT_DETECT_THREADS - 1) / MRT_DETECT_THREADS;
+	hipLaunchKernelGGL(detect_grid_kernel, dim3(blocks), dim3(MRT_DETECT_THREADS), 0, stream, rays, in_fmt, count, tile_w_log2, scratch, out);
+	return hipGetLastError();
 }
 
 // ---- Morton keys: src/dispatch/ray_sort.h:41-76 -------------------------------------
@@ -292,13 +392,25 @@ __global__ __launch_bounds__(MRT_WG) void morton_keys_kernel(const void *rays, u
 hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream)
 {
 	uint64_t threads;
-	if (p.lane_map == MAP_TILE8X8) threads = (uint64_t)p.tiles_x * ((p.rows + 7u) / 8u) * 64u;
-	else threads = p.count;
+	if (p.lane_map == MAP_TILE8X8) {
+		const uint32_t th = 64u >> p.tile_w_log2;
+		threads = (uint64_t)p.tiles_x * ((p.rows + th - 1u) / th) * 64u;
+	} else threads = p.count;
 	if (threads == 0) return hipSuccess;
 	const uint64_t blocks = (threads + MRT_WG - 1) / MRT_WG;
 	if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
-	const size_t lds = (size_t)(MRT_WG / MRT_WAVE) * p.stack_depth * MRT_WAVE * sizeof(uint32_t);
 	dim3 grid((uint32_t)blocks), wg(MRT_WG);
+	if (p.kernel == MRT_KERNEL_PACKET) {
+		if (any_hit) {
+			if (count) hipLaunchKernelGGL((trace_packet_kernel<true, true>), grid, wg, 0, stream, p);
+			else hipLaunchKernelGGL((trace_packet_kernel<true, false>), grid, wg, 0, stream, p);
+		} else {
+			if (count) hipLaunchKernelGGL((trace_packet_kernel<false, true>), grid, wg, 0, stream, p);
+			else hipLaunchKernelGGL((trace_packet_kernel<false, false>), grid, wg, 0, stream, p);
+		}
+		return hipGetLastError();
+	}
+	const size_t lds = (size_t)(MRT_WG / MRT_WAVE) * p.stack_depth * MRT_WAVE * sizeof(uint32_t);
 	if (any_hit) {
 		if (count) hipLaunchKernelGGL((trace_lane_kernel<true, true>), grid, wg, lds, stream, p);
 		else hipLaunchKernelGGL((trace_lane_kernel<true, false>), grid, wg, lds, stream, p);

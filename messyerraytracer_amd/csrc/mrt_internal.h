@@ -47,7 +47,7 @@ constexpr uint32_t kLastInLeaf = 1u;
 
 enum InFmt : uint32_t { IN_RAY32 = 0, IN_HOST60 = 1, IN_GRID = 2 };
 enum OutFmt : uint32_t { OUT_HIT32 = 0, OUT_HOST44 = 1, OUT_BOOL8 = 2 };
-enum LaneMap : uint32_t { MAP_LINEAR = 0, MAP_TILE8X8 = 1 };
+enum LaneMap : uint32_t { MAP_LINEAR = 0, MAP_TILE8X8 = 1, MAP_AUTO = 2 };
 
 struct TraceParams {
 	const DevNode *nodes;
@@ -57,11 +57,14 @@ struct TraceParams {
 	void *hits;                // device
 	const uint32_t *perm;      // optional: lane g traces ray perm[g], writes hits[perm[g]]
 	unsigned long long *counters; // COUNT variants: rays, tri_tests, node_visits, hits, max_stack
+	const uint32_t *auto_grid; // MAP_AUTO: {row width (0 = none), rows, tiles_x} written by detect_grid_kernel
 	uint64_t count;            // number of rays
 	uint32_t query_mask;
 	uint32_t in_fmt, out_fmt, lane_map;
 	uint32_t grid_w, grid_h, y0, rows; // IN_GRID / MAP_TILE8X8: rows [y0, y0+rows) of a grid_w x grid_h grid
-	uint32_t tiles_x;          // ceil(grid_w / 8)
+	uint32_t tiles_x;          // ceil(grid_w / tile width)
+	uint32_t tile_w_log2;      // lane tile: 2^k wide, 64 / 2^k high
+	uint32_t kernel;           // MRT_KERNEL_LANE / MRT_KERNEL_PACKET
 	uint32_t stack_depth;      // LDS stack entries per lane
 	uint32_t xcd_swizzle;      // 1: remap blockIdx so each XCD owns a contiguous band
 	mrt_camera cam;

@@ -333,9 +333,14 @@ static inline int slab(const float bmin[3], const float bmax[3], const float inv
 	return tmin <= tmax;
 }
 
-/* ray_triangle, glsl:105-131 == Triangle::intersect, src/core/triangle.h:56-105 */
+/* ray_triangle, glsl:105-131 == Triangle::intersect, src/core/triangle.h:56-105.
+ * The reference accepts t_min <= t < best_t, so of two triangles with exactly
+ * equal t the one visited first wins, and its BVH2 / BVH4 / BVH8 / GLSL paths
+ * visit in different orders.  Here (and in the HIP kernels) an exact tie goes to
+ * the lower triangle id: best_id is the id of the current best hit, or
+ * 0xFFFFFFFF with have_hit = 0 before any hit. */
 static inline int tri_hit(const orc_tri64 *tr, const float o[3], const float d[3], float t_min, float best_t,
-		float *ot, float *ou, float *ov)
+		int have_hit, uint32_t best_id, float *ot, float *ou, float *ov)
 {
 	float pvec[3], tvec[3], qvec[3];
 	v_cross(d, tr->edge2, pvec);
@@ -349,14 +354,15 @@ static inline int tri_hit(const orc_tri64 *tr, const float o[3], const float d[3
 	float v = v_dot(d, qvec) * inv_det;
 	if (v < 0.0f || u + v > 1.0f) return 0;
 	float t = v_dot(tr->edge2, qvec) * inv_det;
-	if (t < t_min || t >= best_t) return 0;
+	if (t < t_min) return 0;
+	if (!(t < best_t || (t == best_t && have_hit && tr->id < best_id))) return 0;
 	*ot = t; *ou = u; *ov = v;
 	return 1;
 }
 
 int orc_tri_test(const orc_tri64 *tri, const orc_ray32 *ray, float *t, float *u, float *v)
 {
-	return tri_hit(tri, ray->origin, ray->direction, ray->t_min, ray->t_max, t, u, v);
+	return tri_hit(tri, ray->origin, ray->direction, ray->t_min, ray->t_max, 0, 0xFFFFFFFFu, t, u, v);
 }
 
 static inline void write_miss(orc_hit32 *h, float t)
@@ -398,7 +404,7 @@ static void trace_one(const orc_wide64 *wide, const orc_tri64 *lt, const orc_ray
 				if ((tri->layers & mask) == 0u) continue;
 				if (c) c->tri_tests++;
 				float t, u, v;
-				if (tri_hit(tri, o, d, t_min, best_t, &t, &u, &v)) {
+				if (tri_hit(tri, o, d, t_min, best_t, best_slot >= 0, best_slot >= 0 ? lt[best_slot].id : 0xFFFFFFFFu, &t, &u, &v)) {
 					best_t = t; best_u = u; best_v = v; best_slot = (int32_t)(first + k);
 					if (any_hit) goto done;
 				}
@@ -471,7 +477,7 @@ void orc_trace_brute(const orc_tri64 *tris, uint32_t n_tris, const orc_ray32 *ra
 		for (uint32_t k = 0; k < n_tris; k++) {
 			if ((tris[k].layers & query_mask) == 0u) continue;
 			float t, u, v;
-			if (tri_hit(&tris[k], r->origin, r->direction, r->t_min, best_t, &t, &u, &v)) {
+			if (tri_hit(&tris[k], r->origin, r->direction, r->t_min, best_t, best >= 0, best >= 0 ? tris[best].id : 0xFFFFFFFFu, &t, &u, &v)) {
 				best_t = t; bu = u; bv = v; best = k;
 				if (any_hit) break;
 			}

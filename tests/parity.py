@@ -3,9 +3,10 @@
 Two gates ("Parity"):
 
 * HIP kernel vs oracle restatement (same canonical fp32 arithmetic): bit-exact
-  t/u/v/prim_id/normal/layers.  The only admitted difference is an exact tie
-  (two triangles with bitwise-equal t, e.g. a shared edge), where the visiting
-  order picks the winner.
+  t/u/v/prim_id/normal/layers, no exceptions: exact ties (two triangles with
+  bitwise-equal t, e.g. a shared edge) go to the lower triangle id in both, so
+  the answer does not depend on the visiting order, the kernel variant, the
+  lane mapping, the Morton sort or the sharding.
 
 * anything vs the reference's TinyBVH (different fp32 formulas: AVX2 FMA slab,
   approximate reciprocal): prim_id equal except where fp64 arithmetic shows
@@ -69,10 +70,8 @@ def assert_exact(got, want, what=""):
     """HIP kernel vs oracle: bit-exact, exact ties excepted."""
     assert got.shape == want.shape
     diff = np.nonzero(got["prim_id"] != want["prim_id"])[0]
-    for i in diff:
-        assert got["prim_id"][i] >= 0 and want["prim_id"][i] >= 0 and got["t"][i] == want["t"][i], \
-            f"{what}: ray {i}: prim {got['prim_id'][i]} t={got['t'][i]!r} vs oracle prim {want['prim_id'][i]} t={want['t'][i]!r}"
-    assert diff.size <= max(4, got.shape[0] // 1000), f"{what}: {diff.size} exact ties is implausible"
+    assert diff.size == 0, (f"{what}: {diff.size} prim_id differences vs the oracle, first at ray {diff[0]}: "
+                            f"prim {got['prim_id'][diff[0]]} t={got['t'][diff[0]]!r} vs {want['prim_id'][diff[0]]} t={want['t'][diff[0]]!r}")
     same = got["prim_id"] == want["prim_id"]
     for f in ("t", "bary_u", "bary_v", "hit_layers"):
         assert np.array_equal(got[f][same], want[f][same]), f"{what}: field {f} differs from the oracle"

@@ -268,7 +268,7 @@ def test_morton_keys_on_device(ctx):
 
 
 def test_counting_variant_matches_oracle_counters(built):
-    c = capi.Context(0, count_visits=True)
+    c = capi.Context(0, kernel=capi.KERNEL_LANE, count_visits=True)
     v = synth.soup(20000, 0.2, 3)
     scene, osc = capi.Scene(v), po.OracleScene(v)
     scene.upload(c)
@@ -283,6 +283,80 @@ def test_counting_variant_matches_oracle_counters(built):
     assert ctr["node_visits"] <= s["bvh_nodes_visited"] <= 1.35 * ctr["node_visits"]
     assert ctr["tri_tests"] <= s["tri_tests"] <= 1.5 * ctr["tri_tests"]
     assert s["max_stack_depth"] <= c.scene_info()["stack_need"]
+    c.close()
+    # packet kernel: a wave visits the union of its lanes' nodes, charged to every lane
+    c = capi.Context(0, kernel=capi.KERNEL_PACKET, count_visits=True)
+    scene.upload(c)
+    parity.assert_exact(c.cast(rays, flags=capi.FLAG_COHERENT), want, "counting packet variant")
+    s = c.stats()
+    assert s["hits"] == ctr["hits"] and s["bvh_nodes_visited"] >= ctr["node_visits"] and s["tri_tests"] >= ctr["tri_tests"]
+    assert s["dead_pops"] < s["bvh_nodes_visited"]
+    c.close()
+
+
+def test_row_width_detection_for_coherent_batches(built):
+    """mrt_cast(COHERENT) gets no image width (the reference's cast_rays has none): the
+    device looks for it.  Whatever it finds, the results are the oracle's."""
+    c = capi.Context(0, count_visits=True)
+    v = synth.soup(5000, 0.3, 29)
+    scene, osc = capi.Scene(v), po.OracleScene(v)
+    scene.upload(c)
+    cases = []
+    for (w, h, expect) in ((128, 64, 128), (256, 40, 256), (64, 64, 64), (100, 64, 0), (128, 60, 0), (24, 200, 24)):
+        cases.append((po.grid_rays((0, 0, -12), (0, 0, 1), w, h, 50.0), expect, f"{w}x{h}"))
+    a = po.grid_rays((0, 0, -12), (0, 0, 1), 128, 32, 50.0)
+    b = po.grid_rays((0, 0, -12), (0, 0, 1), 64, 64, 50.0)
+    cases.append((np.concatenate([a, b]), None, "two grids glued"))   # width changes half way: any answer is fine
+    cases.append((synth.incoherent_rays(8192, 3), 0, "incoherent rays declared coherent"))
+    same = po.grid_rays((0, 0, -12), (0, 0, 1), 64, 64, 50.0)
+    same["direction"][:] = same["direction"][0]
+    cases.append((same, 0, "identical directions"))
+    for rays, expect, name in cases:
+        want = osc.trace(rays)
+        got = c.cast(rays, flags=capi.FLAG_COHERENT)
+        parity.assert_exact(got, want, name)
+        s = c.stats()
+        assert s["last_kernel_launches"] == 2
+        if expect is not None:
+            assert s["detected_grid_w"] == expect, (name, s["detected_grid_w"])
+        host = po.make_host_rays(rays)
+        got44 = c.cast(host, flags=capi.FLAG_COHERENT | capi.FLAG_HOST_LAYOUT)
+        assert got44.tobytes() == po.unpack_hits(want, host).tobytes()
+    c.close()
+
+
+@pytest.mark.parametrize("kernel", [capi.KERNEL_LANE, capi.KERNEL_PACKET])
+def test_both_kernels_on_every_kind_of_batch(built, kernel):
+    """Either kernel must give the oracle's answer for any batch, coherent or not:
+    the kernel choice (MRT_KERNEL_AUTO) is a speed decision only."""
+    c = capi.Context(0, kernel=kernel)
+    v = synth.soup(3000, 0.35, 17)
+    layers = (1 << (np.arange(3000) % 3)).astype(np.uint32)
+    scene, osc = capi.Scene(v, None, layers), po.OracleScene(v, None, layers)
+    scene.upload(c)
+    grid = po.grid_rays((0, 0, -12), (0, 0, 1), 100, 70, 50.0)          # ragged tiles: 100 x 70
+    inc = synth.incoherent_rays(5000, 23)
+    inc["t_min"][:300] = 3.0
+    inc["t_max"][:300] = 3.0                                             # degenerate
+    inc["direction"][300:600] = [1, 0, 0]                                # axis aligned
+    inc["t_max"][600:900] = 1.5
+    mixed = np.concatenate([grid[:777], inc[:1000]])                     # mixed octants inside waves
+    for rays, name in ((grid, "grid"), (inc, "incoherent"), (mixed, "mixed")):
+        for mask in (0xFFFFFFFF, 0x5):
+            want = osc.trace(rays, query_mask=mask)
+            for flags in (capi.FLAG_COHERENT, 0):
+                parity.assert_exact(c.cast(rays, query_mask=mask, flags=flags), want, f"{name} mask={mask:#x} flags={flags}")
+            b = c.cast(rays, query_mask=mask, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_COHERENT | capi.FLAG_BOOL_OUT)
+            assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
+    cam = capi.camera_look((0, 0, -12), (0, 0, 1), 100, 70, 50.0)
+    want = osc.trace(grid)
+    parity.assert_exact(c.cast_grid(cam, 100, 70), want, "cast_grid ragged tiles")
+    parity.assert_exact(c.cast_grid(cam, 100, 70, y0=13, y1=41), want[13 * 100:41 * 100], "cast_grid row window")
+    for k in (1, 2, 4, 5, 6):
+        ck = capi.Context(0, kernel=kernel, tile_w_log2=k)
+        scene.upload(ck)
+        parity.assert_exact(ck.cast_grid(cam, 100, 70), want, f"tile 2^{k}")
+        ck.close()
     c.close()
 
 
