@@ -52,7 +52,8 @@ def cpu_baseline(cfg, verts):
     same 4096^2 grid after a warm-up pass over 1/8 of it).  Checker code, used here only
     as the reported baseline."""
     from oracle import pyoracle as po
-    cores = len(os.sched_getaffinity(0))
+    # the box's CPU share for one GPU is 16 cores; never spawn more workers than that
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("MRT_CPU_BASELINE_THREADS", "16")))
     w, h = cfg["grid"]
     rays = po.grid_rays(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
     if po.ref_available():
@@ -159,7 +160,7 @@ def main():
         stats_path = os.path.join(ROOT, "tests", "golden", "traversal_stats.json")
         kernel_ms = float(np.sum(trace_ms)) / a.steps          # per step (all chunks), rank 0
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "trace_lane_kernel<false,false>", "kernel_ms": kernel_ms}
+                "kernel": "trace_packet_kernel<false,false>", "kernel_ms": kernel_ms}
         if os.path.exists(stats_path):
             st = json.load(open(stats_path)).get(a.config)
             if st:

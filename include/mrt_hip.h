@@ -173,7 +173,8 @@ typedef struct mrt_options {
 	uint32_t xcd_swizzle;     /* 1: give each XCD a contiguous band of the batch (default: the hardware's
 	                             round-robin placement, which balances cheap and expensive image regions) */
 	uint32_t stack_override;  /* LDS stack entries per lane (lane kernel), >= what the BVH needs    */
-	uint32_t reserved[8];
+	uint32_t tile_order;      /* 1: tiles in row-major order, 2: Z-order inside 16x16-tile super-tiles */
+	uint32_t reserved[7];
 } mrt_options;
 
 typedef struct mrt_ctx mrt_ctx;

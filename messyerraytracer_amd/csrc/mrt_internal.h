@@ -64,6 +64,7 @@ struct TraceParams {
 	uint32_t grid_w, grid_h, y0, rows; // IN_GRID / MAP_TILE8X8: rows [y0, y0+rows) of a grid_w x grid_h grid
 	uint32_t tiles_x;          // ceil(grid_w / tile width)
 	uint32_t tile_w_log2;      // lane tile: 2^k wide, 64 / 2^k high
+	uint32_t tile_order;       // 0: tiles row-major, 1: Z-order inside 16x16-tile super-tiles
 	uint32_t kernel;           // MRT_KERNEL_LANE / MRT_KERNEL_PACKET
 	uint32_t stack_depth;      // LDS stack entries per lane
 	uint32_t xcd_swizzle;      // 1: remap blockIdx so each XCD owns a contiguous band

@@ -32,6 +32,9 @@ VARIANTS = {
     "packet_tile16x4": (dict(kernel=capi.KERNEL_PACKET, tile_w_log2=4), "tiled"),
     "packet_tile8x8_swz": (dict(kernel=capi.KERNEL_PACKET, xcd_swizzle=1), "tiled"),
     "packet_tile4x16": (dict(kernel=capi.KERNEL_PACKET, tile_w_log2=2), "tiled"),
+    "packet_tile8x8_zorder": (dict(kernel=capi.KERNEL_PACKET, tile_order=2), "tiled"),
+    "packet_tile8x8_zorder_swz": (dict(kernel=capi.KERNEL_PACKET, tile_order=2, xcd_swizzle=1), "tiled"),
+    "lane_tile8x8_zorder": (dict(kernel=capi.KERNEL_LANE, tile_order=2), "tiled"),
     "auto_cast": (dict(), "cast"),
     "auto_tiled": (dict(), "tiled"),
 }

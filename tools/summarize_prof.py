@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 CSV output of one round (gpurun_out/<dir>) into the committed
+summaries under profiles/: per-kernel time (kernel-trace --stats) and per-launch PMC
+counters of the trace kernel, plus profiles/pmc_traffic.json that bench.py reports as
+roofline.traffic.
+
+    python tools/summarize_prof.py gpurun_out/r1 r01 [--config C3] [--kernel trace_packet]
+
+HBM bytes follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: FETCH_SIZE and
+WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half the bytes of wide coalesced
+reads, so the read side is given both raw and doubled (the doubled figure is the
+upper bound used for `traffic`); WRITE_SIZE is exact for 16-byte-per-lane stores.
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    config = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "C3"
+    kernel = sys.argv[sys.argv.index("--kernel") + 1] if "--kernel" in sys.argv else "trace_packet"
+    out_dir = os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    summary = {"round": tag, "config": config, "kernel_filter": kernel}
+    for f in glob.glob(os.path.join(src, "kt", "*", "*_kernel_stats.csv")):
+        shutil.copy(f, os.path.join(out_dir, f"{tag}_kernel_stats.csv"))
+        rows = list(csv.DictReader(open(f)))
+        summary["kernel_stats"] = [{k: r[k] for k in ("Name", "Calls", "AverageNs", "Percentage", "MinNs", "MaxNs")} for r in rows]
+    bench = os.path.join(src, "kt_bench.json")
+    if os.path.exists(bench):
+        summary["bench_line_under_rocprof"] = json.load(open(bench))
+    counters = defaultdict(list)
+    for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if kernel in r["Kernel_Name"]:
+                counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                summary.setdefault("launch", {"grid": r["Grid_Size"], "workgroup": r["Workgroup_Size"], "lds": r["LDS_Block_Size"],
+                                              "vgpr": r["VGPR_Count"], "sgpr": r["SGPR_Count"], "scratch": r["Scratch_Size"]})
+    pmc = {k: sum(v) / len(v) for k, v in sorted(counters.items())}
+    summary["pmc_per_launch_mean"] = pmc
+    if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+        rd_raw, wr = pmc["FETCH_SIZE"] * 1024.0, pmc["WRITE_SIZE"] * 1024.0
+        summary["hbm_bytes_per_launch"] = {"read_raw": rd_raw, "read_x2_gfx950": 2 * rd_raw, "write": wr,
+                                           "total_upper": 2 * rd_raw + wr}
+        tp = os.path.join(out_dir, "pmc_traffic.json")
+        traffic = json.load(open(tp)) if os.path.exists(tp) else {}
+        traffic[config] = {"hbm_bytes_per_launch": 2 * rd_raw + wr, "read_raw": rd_raw, "write": wr, "round": tag,
+                           "note": "FETCH_SIZE*1024*2 (gfx950 half-count correction) + WRITE_SIZE*1024, mean over profiled launches"}
+        json.dump(traffic, open(tp, "w"), indent=1, sort_keys=True)
+    if "TCC_HIT_sum" in pmc:
+        summary["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
+    if "SQ_WAVE_CYCLES" in pmc:
+        wc = pmc["SQ_WAVE_CYCLES"]
+        summary["wave_cycle_shares"] = {k: pmc[k] / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU") if k in pmc}
+        if "SQ_WAVES" in pmc:
+            summary["per_wave"] = {k: pmc[k] / pmc["SQ_WAVES"] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS",
+                                                                           "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR") if k in pmc}
+    with open(os.path.join(out_dir, f"{tag}_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()
