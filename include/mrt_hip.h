@@ -159,7 +159,8 @@ enum {
 enum {
 	MRT_KERNEL_AUTO = 0,
 	MRT_KERNEL_LANE = 1,    /* one lane = one ray, per-lane LDS stack, while-while loop         */
-	MRT_KERNEL_PACKET = 2   /* one wave = one 64-ray packet, per-wave LDS stack, scalar fetches */
+	MRT_KERNEL_PACKET = 2,  /* one wave = one 64-ray packet, per-wave LDS stack, scalar fetches */
+	MRT_KERNEL_PACKET4 = 3  /* packet walk over the 4-wide collapse of the same BVH2 (128-B fetches) */
 };
 
 typedef struct mrt_options {

@@ -13,6 +13,7 @@
 //
 // Compiled with -ffp-contract=off: every rounding is the one written.
 #include <cmath>
+#include <limits>
 #include <cfloat>
 #include <cstdio>
 #include <cstdlib>
@@ -172,6 +173,65 @@ int prepare_scene(const mrt_tri64 *tris, uint32_t n_tris, const mrt_bvh_node32 *
 	std::memcpy(out->nodes, dev.data(), dev.size() * sizeof(DevNode));
 	out->hot = hot; out->cold = cold; out->n_tris = n_tris;
 	out->depth = depth + 1; // one pending entry per wide node on the current path + the sentinel
+
+	// ---- 4-wide collapse of the same tree for the packet kernel ----
+	// Children of a 4-node: start from the two children of a BVH2 node and keep opening the
+	// internal child with the largest half-area until there are four (or only leaves remain).
+	{
+		struct Child { float mn[3], mx[3]; uint32_t ref; };
+		auto area = [](const Child &c) {
+			const float e0 = c.mx[0] - c.mn[0], e1 = c.mx[1] - c.mn[1], e2 = c.mx[2] - c.mn[2];
+			return e0 * e1 + e1 * e2 + e2 * e0;
+		};
+		auto children_of = [&](uint32_t w, Child &l, Child &r) {
+			const DevNode &g = dev[w];
+			for (int c = 0; c < 3; c++) { l.mn[c] = g.lmin[c]; l.mx[c] = g.lmax[c]; r.mn[c] = g.rmin[c]; r.mx[c] = g.rmax[c]; }
+			l.ref = g.left_ref; r.ref = g.right_ref;
+		};
+		struct Work { uint32_t w2, idx4, need; };
+		std::vector<Dev4Node> dev4;
+		std::vector<Work> work;
+		dev4.emplace_back();
+		work.push_back({ 0u, 0u, 0u });
+		uint32_t stack4 = 1;
+		while (!work.empty()) {
+			const Work wk = work.back(); work.pop_back();
+			Child ch[4]; uint32_t n = 2;
+			children_of(wk.w2, ch[0], ch[1]);
+			while (n < 4) {
+				int best = -1; float best_a = -1.0f;
+				for (uint32_t i = 0; i < n; i++) if (ch[i].ref < kSentinel) { const float a = area(ch[i]); if (a > best_a) { best_a = a; best = (int)i; } }
+				if (best < 0) break;
+				Child l, r; children_of(ch[best].ref, l, r);
+				ch[best] = l; ch[n++] = r;
+			}
+			const uint32_t need = wk.need + (n - 1);
+			if (need + 1 > stack4) stack4 = need + 1;
+			Dev4Node node{};
+			node.n_children = n;
+			for (uint32_t i = 0; i < 4; i++) {
+				if (i < n) {
+					for (int c = 0; c < 3; c++) { node.box[i][c] = ch[i].mn[c]; node.box[i][3 + c] = ch[i].mx[c]; }
+					if (ch[i].ref < kSentinel) {
+						const uint32_t idx = (uint32_t)dev4.size();
+						dev4.emplace_back();
+						work.push_back({ ch[i].ref, idx, need });
+						node.ref[i] = idx;
+					} else node.ref[i] = ch[i].ref;
+				} else {
+					// unused slot: the point box at +inf; its slab test fails for every finite ray interval
+					for (int c = 0; c < 6; c++) node.box[i][c] = std::numeric_limits<float>::infinity();
+					node.ref[i] = kSentinel;
+				}
+			}
+			dev4[wk.idx4] = node;
+		}
+		out->n_nodes4 = (uint32_t)dev4.size();
+		out->nodes4 = (Dev4Node *)std::malloc(dev4.size() * sizeof(Dev4Node));
+		if (!out->nodes4) { std::free(hot); std::free(cold); std::free(out->nodes); out->nodes = nullptr; return fail(MRT_ERR_OOM, "upload_scene: out of host memory"); }
+		std::memcpy(out->nodes4, dev4.data(), dev4.size() * sizeof(Dev4Node));
+		out->stack4 = stack4;
+	}
 	return MRT_OK;
 }
 

@@ -11,6 +11,7 @@
 // __builtin_fmaf, so results are bit-identical to oracle/mrt_oracle.c.
 #include <hip/hip_runtime.h>
 #include <cfloat>
+#include <cstdlib>
 #include "mrt_internal.h"
 
 namespace mrt {
@@ -263,6 +264,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 }
 
 #include "packet_kernel.h"
+#include "packet4_kernel.h"
 
 // ---- standalone ray generation (mrt_generate_grid) ---------------------------------
 __global__ __launch_bounds__(MRT_WG) void grid_rays_kernel(const TraceParams p, mrt_ray32 *out)
@@ -411,13 +413,25 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 	const uint64_t blocks = (threads + MRT_WG - 1) / MRT_WG;
 	if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
 	dim3 grid((uint32_t)blocks), wg(MRT_WG);
-	if (p.kernel == MRT_KERNEL_PACKET) {
+	if (p.kernel == MRT_KERNEL_PACKET4) {
 		if (any_hit) {
-			if (count) hipLaunchKernelGGL((trace_packet_kernel<true, true>), grid, wg, 0, stream, p);
-			else hipLaunchKernelGGL((trace_packet_kernel<true, false>), grid, wg, 0, stream, p);
+			if (count) hipLaunchKernelGGL((trace_packet4_kernel<true, true>), grid, wg, 0, stream, p);
+			else hipLaunchKernelGGL((trace_packet4_kernel<true, false>), grid, wg, 0, stream, p);
 		} else {
-			if (count) hipLaunchKernelGGL((trace_packet_kernel<false, true>), grid, wg, 0, stream, p);
-			else hipLaunchKernelGGL((trace_packet_kernel<false, false>), grid, wg, 0, stream, p);
+			if (count) hipLaunchKernelGGL((trace_packet4_kernel<false, true>), grid, wg, 0, stream, p);
+			else hipLaunchKernelGGL((trace_packet4_kernel<false, false>), grid, wg, 0, stream, p);
+		}
+		return hipGetLastError();
+	}
+	if (p.kernel == MRT_KERNEL_PACKET) {
+		// experiment knob: extra (unused) dynamic LDS per workgroup lowers the occupancy
+		static const size_t pad = [] { const char *e = getenv("MRT_EXP_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
+		if (any_hit) {
+			if (count) hipLaunchKernelGGL((trace_packet_kernel<true, true>), grid, wg, pad, stream, p);
+			else hipLaunchKernelGGL((trace_packet_kernel<true, false>), grid, wg, pad, stream, p);
+		} else {
+			if (count) hipLaunchKernelGGL((trace_packet_kernel<false, true>), grid, wg, pad, stream, p);
+			else hipLaunchKernelGGL((trace_packet_kernel<false, false>), grid, wg, pad, stream, p);
 		}
 		return hipGetLastError();
 	}

@@ -41,6 +41,18 @@ struct alignas(16) TriHot {
 static_assert(sizeof(TriHot) == 48, "TriHot must be 48 bytes");
 struct alignas(16) TriCold { float normal[3]; uint32_t pad; };
 
+// 4-wide node for the packet kernel: two levels of the BVH2 collapsed into one 128-byte
+// fetch (2 x s_load_dwordx16), halving the chain of dependent fetches a packet walks.
+// Built on the host from the same binned-SAH BVH2 (greedy: keep opening the child with
+// the largest surface area until there are 4).  Child refs use the DevNode encoding with
+// wide4 indices; an unused slot has ref == kSentinel.
+struct alignas(16) Dev4Node {
+	float box[4][6];      // child c: min.xyz, max.xyz
+	uint32_t ref[4];
+	uint32_t n_children, pad[3];
+};
+static_assert(sizeof(Dev4Node) == 128, "Dev4Node must be 128 bytes");
+
 constexpr uint32_t kSentinel = 0x7FFFFFFFu;
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kLastInLeaf = 1u;
@@ -51,6 +63,7 @@ enum LaneMap : uint32_t { MAP_LINEAR = 0, MAP_TILE8X8 = 1, MAP_AUTO = 2 };
 
 struct TraceParams {
 	const DevNode *nodes;
+	const Dev4Node *nodes4;    // packet kernel, 4-wide layout (may be null)
 	const TriHot *tri_hot;
 	const TriCold *tri_cold;
 	const void *rays;          // IN_RAY32 / IN_HOST60 (device)
@@ -74,6 +87,8 @@ struct TraceParams {
 // host-side preparation (scene_prep.cpp)
 struct DeviceSceneHost {
 	DevNode *nodes = nullptr; uint32_t n_nodes = 0;
+	Dev4Node *nodes4 = nullptr; uint32_t n_nodes4 = 0;
+	uint32_t stack4 = 0;        // per-wave stack entries the 4-wide walk can need
 	TriHot *hot = nullptr; TriCold *cold = nullptr; uint32_t n_tris = 0;
 	uint32_t depth = 0;         // max stack entries any traversal can need (incl. sentinel)
 };
