@@ -18,7 +18,7 @@ MRT_OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SCENE, ERR_PENDING, ERR_NOT_PENDING, ERR_OOM, ERR_UNSUPPORTED, ERR_BAD_BVH = range(1, 10)
 MODE_NEAREST, MODE_ANY_HIT = 0, 1
 FLAG_COHERENT, FLAG_RAYS_ON_DEVICE, FLAG_HITS_ON_DEVICE, FLAG_HOST_LAYOUT, FLAG_BOOL_OUT, FLAG_FORCE_SORT = (1 << i for i in range(6))
-KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET, KERNEL_PACKET4 = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET, KERNEL_PACKET4, KERNEL_PACKET2, KERNEL_PACKET_ASM = 0, 1, 2, 3, 4, 5
 
 # every entry point include/mrt_hip.h declares (tests check they are all exported)
 SYMBOLS = [

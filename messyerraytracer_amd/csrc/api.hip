@@ -117,11 +117,13 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 // primary-ray grids), one lane per ray for everything else (sorted / incoherent batches).
 uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent)
 {
-	if (ctx->opts.kernel == MRT_KERNEL_LANE || ctx->opts.kernel == MRT_KERNEL_PACKET || ctx->opts.kernel == MRT_KERNEL_PACKET4)
+	if (ctx->opts.kernel == MRT_KERNEL_LANE || ctx->opts.kernel == MRT_KERNEL_PACKET || ctx->opts.kernel == MRT_KERNEL_PACKET4 ||
+			ctx->opts.kernel == MRT_KERNEL_PACKET2 || ctx->opts.kernel == MRT_KERNEL_PACKET_ASM)
 		return ctx->opts.kernel;
 	// (PACKET4 halves the fetch chain but measured 7 % slower at C3: the walk is bound by
 	// instruction issue, and ordering four children costs more scalar work than it saves)
-	return coherent ? MRT_KERNEL_PACKET : MRT_KERNEL_LANE;
+	// PACKET_ASM: same walk with the hand-written node loop (the compiler's loop is scalar-ALU bound)
+	return coherent ? MRT_KERNEL_PACKET_ASM : MRT_KERNEL_LANE;
 }
 
 int drain_pending(mrt_ctx *ctx)
@@ -321,7 +323,8 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	hipError_t e;
 	const bool want4 = ctx->opts.kernel == MRT_KERNEL_PACKET4; // the 4-wide layout is resident only when asked for
 	if ((e = hipMalloc(&ctx->d_nodes, (size_t)h.n_nodes * sizeof(mrt::DevNode))) != hipSuccess ||
-			(e = hipMalloc(&ctx->d_hot, (size_t)h.n_tris * sizeof(mrt::TriHot))) != hipSuccess ||
+			// +16 B: the dual-packet kernel fetches 64 B at a 48-B triangle (the tail is never used)
+			(e = hipMalloc(&ctx->d_hot, (size_t)h.n_tris * sizeof(mrt::TriHot) + 16)) != hipSuccess ||
 			(e = hipMalloc(&ctx->d_cold, (size_t)h.n_tris * sizeof(mrt::TriCold))) != hipSuccess ||
 			(want4 && (e = hipMalloc(&ctx->d_nodes4, (size_t)h.n_nodes4 * sizeof(mrt::Dev4Node))) != hipSuccess)) {
 		cleanup(); free_scene(ctx);

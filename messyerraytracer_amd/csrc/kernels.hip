@@ -40,9 +40,14 @@ struct RayRegs {
 // ---- lane -> ray mapping ---------------------------------------------------------
 // MAP_LINEAR: thread g traces ray g (or perm[g]).  MAP_TILE8X8: a wave owns an
 // 8x8 pixel tile of the row-major grid so its 64 rays share most of their path.
+__device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t g, uint64_t &ray_idx, uint32_t &px, uint32_t &py);
 __device__ __forceinline__ bool lane_ray_index(const TraceParams &p, uint32_t block, uint64_t &ray_idx, uint32_t &px, uint32_t &py)
 {
-	const uint64_t g = (uint64_t)block * MRT_WG + threadIdx.x;
+	return lane_ray_index_g(p, (uint64_t)block * MRT_WG + threadIdx.x, ray_idx, px, py);
+}
+// g = virtual thread index: 64 consecutive g form one wave-sized group of rays
+__device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t g, uint64_t &ray_idx, uint32_t &px, uint32_t &py)
+{
 	uint32_t lane_map = p.lane_map, grid_w = p.grid_w, rows = p.rows, tiles_x = p.tiles_x;
 	if (lane_map == MAP_AUTO) { // row width found on the device by detect_grid_kernel (0 = not a grid)
 		const uint32_t w = p.auto_grid[0];
@@ -265,6 +270,8 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 
 #include "packet_kernel.h"
 #include "packet4_kernel.h"
+#include "packet2_kernel.h"
+#include "packet_asm_kernel.h"
 
 // ---- standalone ray generation (mrt_generate_grid) ---------------------------------
 __global__ __launch_bounds__(MRT_WG) void grid_rays_kernel(const TraceParams p, mrt_ray32 *out)
@@ -413,6 +420,23 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 	const uint64_t blocks = (threads + MRT_WG - 1) / MRT_WG;
 	if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
 	dim3 grid((uint32_t)blocks), wg(MRT_WG);
+	if (p.kernel == MRT_KERNEL_PACKET_ASM && !count) { // counting builds use the C++ packet kernel
+		if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true>), grid, wg, 0, stream, p);
+		else hipLaunchKernelGGL((trace_packet_asm_kernel<false>), grid, wg, 0, stream, p);
+		return hipGetLastError();
+	}
+	if (p.kernel == MRT_KERNEL_PACKET2) { // two 64-ray groups per wave: half the workgroups
+		const uint64_t blocks2 = (threads + 2 * MRT_WG - 1) / (2 * MRT_WG);
+		dim3 grid2((uint32_t)blocks2);
+		if (any_hit) {
+			if (count) hipLaunchKernelGGL((trace_packet2_kernel<true, true>), grid2, wg, 0, stream, p);
+			else hipLaunchKernelGGL((trace_packet2_kernel<true, false>), grid2, wg, 0, stream, p);
+		} else {
+			if (count) hipLaunchKernelGGL((trace_packet2_kernel<false, true>), grid2, wg, 0, stream, p);
+			else hipLaunchKernelGGL((trace_packet2_kernel<false, false>), grid2, wg, 0, stream, p);
+		}
+		return hipGetLastError();
+	}
 	if (p.kernel == MRT_KERNEL_PACKET4) {
 		if (any_hit) {
 			if (count) hipLaunchKernelGGL((trace_packet4_kernel<true, true>), grid, wg, 0, stream, p);
@@ -423,7 +447,7 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		}
 		return hipGetLastError();
 	}
-	if (p.kernel == MRT_KERNEL_PACKET) {
+	if (p.kernel == MRT_KERNEL_PACKET || p.kernel == MRT_KERNEL_PACKET_ASM) {
 		// experiment knob: extra (unused) dynamic LDS per workgroup lowers the occupancy
 		static const size_t pad = [] { const char *e = getenv("MRT_EXP_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
 		if (any_hit) {

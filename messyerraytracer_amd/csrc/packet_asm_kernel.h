@@ -1,0 +1,210 @@
+// packet_asm_kernel.h — the packet kernel with a hand-written gfx950 node loop.
+// Included by kernels.hip (inside namespace mrt, after packet_kernel.h).
+//
+// Why: the scalar ALU is ONE unit per CU, ~1 instruction per cycle for all 32 waves
+// (tools/ubench/salu_rate.hip: 0.97 per CU per cycle from 4 waves up).  The compiler's
+// packet loop spends ~30 scalar instructions per node step (structurised control flow,
+// popcount votes, 64-bit address arithmetic): 5.2 k per wave, 5.4 M per CU per launch,
+// i.e. 2.3 ms of a 3.3 ms launch at C3 — the walk was scalar-ALU bound, which is also
+// why the 4-wide and two-packets-per-wave variants, both heavier on scalar work, lost.
+//
+// This loop keeps scalar work to ~5 instructions per step:
+//   * the two child masks come straight out of v_cmp (VCC and an SGPR pair) and are
+//     consumed by s_cbranch_vccz / one s_cmp_eq_u64 — no s_cselect/s_and chains;
+//   * near/far order is lane 0's `tl < tr` (v_cmp + s_bitcmp1 + 2 s_cselect) instead
+//     of two popcount votes: order only affects speed, never results;
+//   * the per-wave stack is addressed through a VGPR (uniform LDS byte address), with a
+//     sentinel at the bottom, so push/pop cost no scalar instruction and there is no
+//     empty-stack test;
+//   * one s_load_dwordx16 with an SGPR offset fetches the 64-byte node.
+// The slab test is the octant-specialised one of packet_kernel.h: 12 v_fma + 8
+// v_max/v_min(3) + 2 v_cmp, bit-identical values.  Leaves (triangle tests) stay in C++.
+// Packets whose rays do not share one octant, and counting builds, use packet_traverse.
+#pragma once
+
+// node registers after the s_load_dwordx16 into s[36:51]:
+//   s36..s38 lmin.xyz  s39 left_ref | s40..s42 lmax.xyz  s43 right_ref
+//   s44..s46 rmin.xyz  s47 -        | s48..s50 rmax.xyz  s51 -
+// scratch: s52 byte offset, s53 far ref, s[54:55] right-child mask, v40..v51 slab values.
+#define MRT_ASM_NODE_LOOP(LNX, LFX, LNY, LFY, LNZ, LFZ, RNX, RFX, RNY, RFY, RNZ, RFZ)                      \
+	asm volatile(                                                                                           \
+		"s_cmp_eq_u32 %[dopop], 1\n"                                                                        \
+		"s_cbranch_scc1 L_pop_%=\n"                                                                         \
+		"s_branch L_check_%=\n"                                                                             \
+		"L_node_%=:\n"                                                                                      \
+		"s_lshl_b32 s52, %[node], 6\n"                                                                      \
+		"s_load_dwordx16 s[36:51], %[base], s52\n"                                                          \
+		"s_waitcnt lgkmcnt(0)\n"                                                                            \
+		"v_fma_f32 v40, " LNX ", %[ix], %[nrx]\n"                                                           \
+		"v_fma_f32 v41, " LNY ", %[iy], %[nry]\n"                                                           \
+		"v_fma_f32 v42, " LNZ ", %[iz], %[nrz]\n"                                                           \
+		"v_fma_f32 v43, " LFX ", %[ix], %[nrx]\n"                                                           \
+		"v_fma_f32 v44, " LFY ", %[iy], %[nry]\n"                                                           \
+		"v_fma_f32 v45, " LFZ ", %[iz], %[nrz]\n"                                                           \
+		"v_fma_f32 v46, " RNX ", %[ix], %[nrx]\n"                                                           \
+		"v_fma_f32 v47, " RNY ", %[iy], %[nry]\n"                                                           \
+		"v_fma_f32 v48, " RNZ ", %[iz], %[nrz]\n"                                                           \
+		"v_fma_f32 v49, " RFX ", %[ix], %[nrx]\n"                                                           \
+		"v_fma_f32 v50, " RFY ", %[iy], %[nry]\n"                                                           \
+		"v_fma_f32 v51, " RFZ ", %[iz], %[nrz]\n"                                                           \
+		"v_max_f32 v42, v42, %[tmin]\n"                                                                     \
+		"v_max3_f32 v40, v40, v41, v42\n"   /* tl  = entry of the left box, clamped to t_min */          \
+		"v_min_f32 v45, v45, %[lim]\n"                                                                      \
+		"v_min3_f32 v43, v43, v44, v45\n"   /* tlx = exit of the left box, clamped to best_t */          \
+		"v_max_f32 v48, v48, %[tmin]\n"                                                                     \
+		"v_max3_f32 v46, v46, v47, v48\n"   /* tr  */                                                    \
+		"v_min_f32 v51, v51, %[lim]\n"                                                                      \
+		"v_min3_f32 v49, v49, v50, v51\n"   /* trx */                                                    \
+		"v_cmp_le_f32 vcc, v40, v43\n"      /* lanes that hit the left child  */                         \
+		"v_cmp_le_f32_e64 s[54:55], v46, v49\n" /* lanes that hit the right child */                         \
+		"s_cbranch_vccz L_lmiss_%=\n"                                                                       \
+		"s_cmp_eq_u64 s[54:55], 0\n"                                                                        \
+		"s_cbranch_scc1 L_onlyl_%=\n"                                                                       \
+		"v_cmp_lt_f32 vcc, v40, v46\n"      /* both hit: lane 0 decides which is nearer */               \
+		"s_bitcmp1_b32 vcc_lo, 0\n"                                                                         \
+		"s_cselect_b32 s53, s43, s39\n"     /* far  */                                                   \
+		"s_cselect_b32 %[node], s39, s43\n" /* near */                                                   \
+		"v_mov_b32 v41, s53\n"                                                                              \
+		"ds_write_b32 %[sp], v41\n"                                                                         \
+		"v_add_u32 %[sp], 4, %[sp]\n"                                                                       \
+		"s_branch L_check_%=\n"                                                                             \
+		"L_onlyl_%=:\n"                                                                                     \
+		"s_mov_b32 %[node], s39\n"                                                                          \
+		"s_branch L_check_%=\n"                                                                             \
+		"L_lmiss_%=:\n"                                                                                     \
+		"s_cmp_eq_u64 s[54:55], 0\n"                                                                        \
+		"s_cbranch_scc1 L_pop_%=\n"                                                                         \
+		"s_mov_b32 %[node], s43\n"                                                                          \
+		"s_branch L_check_%=\n"                                                                             \
+		"L_pop_%=:\n"                                                                                       \
+		"v_add_u32 %[sp], -4, %[sp]\n"                                                                      \
+		"ds_read_b32 v41, %[sp]\n"                                                                          \
+		"s_waitcnt lgkmcnt(0)\n"                                                                            \
+		"v_readfirstlane_b32 %[node], v41\n"                                                                \
+		"L_check_%=:\n"                                                                                     \
+		"s_cmp_lt_u32 %[node], 0x7fffffff\n"                                                                \
+		"s_cbranch_scc1 L_node_%=\n"                                                                        \
+		: [node] "+s"(node), [sp] "+v"(sp)                                                                  \
+		: [base] "s"(base), [dopop] "s"(dopop), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), [nrx] "v"(nrx),   \
+		  [nry] "v"(nry), [nrz] "v"(nrz), [tmin] "v"(tmin), [lim] "v"(lim)                                  \
+		: "memory", "vcc", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45",      \
+		  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "v40", "v41", "v42", "v43", \
+		  "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51")
+
+// Walks inner nodes until `node` is a leaf reference (>= 0x80000000) or the sentinel
+// (0x7FFFFFFF = the stack ran empty).  dopop = 1: start by popping (after a leaf).
+template <int OCT>
+__device__ __forceinline__ void packet_node_loop_asm(const DevNode *base, uint32_t &node, uint32_t &sp, uint32_t dopop,
+		float ix, float iy, float iz, float nrx, float nry, float nrz, float tmin, float lim)
+{
+	// per axis: inv >= 0 -> near plane = min, far plane = max; inv < 0 -> swapped
+	if (OCT == 0) MRT_ASM_NODE_LOOP("s36", "s40", "s37", "s41", "s38", "s42", "s44", "s48", "s45", "s49", "s46", "s50");
+	if (OCT == 1) MRT_ASM_NODE_LOOP("s40", "s36", "s37", "s41", "s38", "s42", "s48", "s44", "s45", "s49", "s46", "s50");
+	if (OCT == 2) MRT_ASM_NODE_LOOP("s36", "s40", "s41", "s37", "s38", "s42", "s44", "s48", "s49", "s45", "s46", "s50");
+	if (OCT == 3) MRT_ASM_NODE_LOOP("s40", "s36", "s41", "s37", "s38", "s42", "s48", "s44", "s49", "s45", "s46", "s50");
+	if (OCT == 4) MRT_ASM_NODE_LOOP("s36", "s40", "s37", "s41", "s42", "s38", "s44", "s48", "s45", "s49", "s50", "s46");
+	if (OCT == 5) MRT_ASM_NODE_LOOP("s40", "s36", "s37", "s41", "s42", "s38", "s48", "s44", "s45", "s49", "s50", "s46");
+	if (OCT == 6) MRT_ASM_NODE_LOOP("s36", "s40", "s41", "s37", "s42", "s38", "s44", "s48", "s49", "s45", "s50", "s46");
+	if (OCT == 7) MRT_ASM_NODE_LOOP("s40", "s36", "s41", "s37", "s42", "s38", "s48", "s44", "s49", "s45", "s50", "s46");
+}
+
+template <int OCT, bool ANY_HIT>
+__device__ __forceinline__ void packet_traverse_asm(const TraceParams &p, const RayRegs &r, uint32_t sp,
+		float &best_t, float &best_u, float &best_v, uint32_t &best_slot)
+{
+	const bool degenerate = r.t_min >= r.t_max;
+	float lim_t = degenerate ? -FLT_MAX : best_t;
+	const float ix = safe_inv(r.dx), iy = safe_inv(r.dy), iz = safe_inv(r.dz);
+	const float nrx = -(r.ox * ix), nry = -(r.oy * iy), nrz = -(r.oz * iz);
+	const float4 *hot = reinterpret_cast<const float4 *>(p.tri_hot);
+	uint32_t best_id = 0xFFFFFFFFu;
+	uint32_t cur = 0; // root: always a wide node
+	uint32_t dopop = 0;
+	for (;;) {
+		packet_node_loop_asm<OCT>(p.nodes, cur, sp, dopop, ix, iy, iz, nrx, nry, nrz, r.t_min, lim_t);
+		cur = __builtin_amdgcn_readfirstlane(cur);
+		if (cur == kSentinel) break;
+		// leaf: every lane tests every triangle of the leaf (glsl:166-192)
+		uint32_t slot = cur & 0x7FFFFFFFu;
+		bool last;
+		do {
+			const float4 *t3 = hot + (size_t)slot * 3u; // uniform address
+			const float4 q0 = t3[0], q1 = t3[1], q2 = t3[2];
+			last = (__float_as_uint(q2.w) & kLastInLeaf) != 0u;
+			if ((__float_as_uint(q1.w) & p.query_mask) != 0u) {
+				// ray_triangle, glsl:105-131 == Triangle::intersect, src/core/triangle.h:56-105
+				const float pvx = fma_(r.dy, q2.z, -(r.dz * q2.y));
+				const float pvy = fma_(r.dz, q2.x, -(r.dx * q2.z));
+				const float pvz = fma_(r.dx, q2.y, -(r.dy * q2.x));
+				const float det = dot3(q1.x, q1.y, q1.z, pvx, pvy, pvz);
+				if (!(__builtin_fabsf(det) < 1e-8f)) {
+					const float inv_det = 1.0f / det;
+					const float tvx = r.ox - q0.x, tvy = r.oy - q0.y, tvz = r.oz - q0.z;
+					const float u = dot3(tvx, tvy, tvz, pvx, pvy, pvz) * inv_det;
+					if (!(u < 0.0f || u > 1.0f)) {
+						const float qvx = fma_(tvy, q1.z, -(tvz * q1.y));
+						const float qvy = fma_(tvz, q1.x, -(tvx * q1.z));
+						const float qvz = fma_(tvx, q1.y, -(tvy * q1.x));
+						const float v = dot3(r.dx, r.dy, r.dz, qvx, qvy, qvz) * inv_det;
+						if (!(v < 0.0f || u + v > 1.0f)) {
+							const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
+							const uint32_t id = __float_as_uint(q0.w);
+							if (!(t < r.t_min) && (t < lim_t || (t == lim_t && best_slot != 0xFFFFFFFFu && id < best_id))) {
+								best_t = t; best_u = u; best_v = v; best_slot = slot; best_id = id;
+								lim_t = ANY_HIT ? -FLT_MAX : t;
+							}
+						}
+					}
+				}
+			}
+			slot++;
+		} while (!last);
+		if (ANY_HIT && __ballot(lim_t != -FLT_MAX) == 0ull) break;
+		dopop = 1;
+	}
+}
+
+template <bool ANY_HIT>
+__global__ __launch_bounds__(MRT_WG) void trace_packet_asm_kernel(const TraceParams p)
+{
+	__shared__ uint32_t wave_stack[MRT_WG / MRT_WAVE][MRT_PACKET_STACK + 1];
+	uint32_t block = blockIdx.x;
+	if (p.xcd_swizzle) {
+		const uint32_t per = gridDim.x >> 3;
+		if (block < (per << 3)) block = (block & 7u) * per + (block >> 3);
+	}
+	uint64_t ray_idx = 0; uint32_t px = 0, py = 0;
+	if (!lane_ray_index(p, block, ray_idx, px, py)) return; // exited lanes drop out of every mask
+	RayRegs r;
+	load_ray(p, ray_idx, px, py, r);
+
+	float best_t = r.t_max, best_u = 0.0f, best_v = 0.0f;
+	uint32_t best_slot = 0xFFFFFFFFu;
+	uint32_t *stack = wave_stack[threadIdx.x / MRT_WAVE];
+
+	const unsigned long long live = __ballot(true);
+	const unsigned long long sx = __ballot(safe_inv(r.dx) < 0.0f), sy = __ballot(safe_inv(r.dy) < 0.0f),
+			sz = __ballot(safe_inv(r.dz) < 0.0f);
+	const bool uniform = (sx == 0ull || sx == live) && (sy == 0ull || sy == live) && (sz == 0ull || sz == live);
+	const int oct = uniform ? ((sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0)) : 8;
+	if (oct == 8) { // mixed directions in one packet: the compiler-scheduled generic walk
+		uint32_t nn = 0, nt = 0, nd = 0;
+		packet_traverse<8, ANY_HIT, false>(p, r, stack, best_t, best_u, best_v, best_slot, nn, nt, nd);
+	} else {
+		// sentinel at the bottom of the per-wave stack; sp = LDS byte address of the next free entry
+		stack[0] = kSentinel;
+		const uint32_t sp = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(stack + 1);
+#define MRT_PKTA(O) case O: packet_traverse_asm<O, ANY_HIT>(p, r, sp, best_t, best_u, best_v, best_slot); break;
+		switch (oct) { MRT_PKTA(0) MRT_PKTA(1) MRT_PKTA(2) MRT_PKTA(3) MRT_PKTA(4) MRT_PKTA(5) MRT_PKTA(6) MRT_PKTA(7) }
+#undef MRT_PKTA
+	}
+
+	int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
+	if (best_slot != 0xFFFFFFFFu) {
+		prim = (int32_t)p.tri_hot[best_slot].id;
+		layers = p.tri_hot[best_slot].layers;
+		const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
+		nx = nn.x; ny = nn.y; nz = nn.z;
+	}
+	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers);
+}

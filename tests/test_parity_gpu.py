@@ -325,7 +325,8 @@ def test_row_width_detection_for_coherent_batches(built):
     c.close()
 
 
-@pytest.mark.parametrize("kernel", [capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET4])
+@pytest.mark.parametrize("kernel", [capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET4, capi.KERNEL_PACKET2,
+                                    capi.KERNEL_PACKET_ASM])
 def test_both_kernels_on_every_kind_of_batch(built, kernel):
     """Either kernel must give the oracle's answer for any batch, coherent or not:
     the kernel choice (MRT_KERNEL_AUTO) is a speed decision only."""
