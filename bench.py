@@ -87,7 +87,11 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run (RANK set) the process group exists even for one rank; with
+    # MRT_REHEARSE_GATHER=1 a single rank also runs the chunked gather (self-gather), which is how
+    # the N > 1 code path is rehearsed on a one-GPU box
+    use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("MRT_REHEARSE_GATHER") == "1")
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)
 
@@ -123,11 +127,11 @@ def main():
             ctx.cast(d_rays.data_ptr() + y0 * w * 32, out, count=(y1 - y0) * w, flags=dev_flags)
         trace_ms.append(ctx.stats()["last_trace_ms"])
 
-    chunks = a.chunks if world > 1 else 1
-    job = sharded.ShardedViews(w, h, tracer, device, chunks=chunks, gather=not a.no_gather)
+    chunks = a.chunks if use_dist else 1
+    job = sharded.ShardedViews(w, h, tracer, device, chunks=chunks, gather=not a.no_gather, force_gather=use_dist)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(device)
 
@@ -140,7 +144,7 @@ def main():
         job.step()
     sync()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -154,13 +158,13 @@ def main():
             "config": {"workload": f"{a.config}: {verts.shape[0]}-triangle soup (seed {cfg.get('seed')}), 8-bin SAH BVH2, "
                                    f"{w}x{h} primary-ray grid per GPU, closest hit, rays+hits HBM-resident",
                        "entry": {"cast": "mrt_cast(COHERENT)", "tiled": "mrt_cast_tiled", "fused": "mrt_cast_grid"}[a.mode],
-                       "views": world, "gather": "rccl gather to rank 0, %d chunks" % chunks if world > 1 and not a.no_gather else "none"},
+                       "views": world, "gather": "rccl gather to rank 0, %d chunks" % chunks if use_dist and not a.no_gather else "none"},
         }
         # roofline of the dominant kernel (trace_lane_kernel): algorithmic bytes / kernel time
         stats_path = os.path.join(ROOT, "tests", "golden", "traversal_stats.json")
         kernel_ms = float(np.sum(trace_ms)) / a.steps          # per step (all chunks), rank 0
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "trace_packet_kernel<false,false>", "kernel_ms": kernel_ms}
+                "kernel": "trace_packet_asm_kernel<false>", "kernel_ms": kernel_ms}
         if os.path.exists(stats_path):
             st = json.load(open(stats_path)).get(a.config)
             if st:
@@ -177,7 +181,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(cfg, verts)
         print(json.dumps(out), flush=True)
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -177,7 +177,9 @@ typedef struct mrt_options {
 	                             round-robin placement, which balances cheap and expensive image regions) */
 	uint32_t stack_override;  /* LDS stack entries per lane (lane kernel), >= what the BVH needs    */
 	uint32_t tile_order;      /* 1: tiles in row-major order, 2: Z-order inside 16x16-tile super-tiles */
-	uint32_t reserved[7];
+	uint32_t sort_key;        /* 0: origin cell + direction Morton key (default), 1: the reference's
+	                             direction-only key (ray_sort.h:64-76); the order never changes results */
+	uint32_t reserved[6];
 } mrt_options;
 
 typedef struct mrt_ctx mrt_ctx;

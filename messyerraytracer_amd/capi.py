@@ -12,7 +12,7 @@ import numpy as np
 from . import types as T
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libmrt_hip.so")
+LIB_PATH = os.environ.get("MRT_LIB_PATH", os.path.join(HERE, "libmrt_hip.so"))  # override: A/B builds in tools/
 
 MRT_OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SCENE, ERR_PENDING, ERR_NOT_PENDING, ERR_OOM, ERR_UNSUPPORTED, ERR_BAD_BVH = range(1, 10)
@@ -40,7 +40,7 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("kernel", C.c_uint32), ("count_visits", C.c_uint32),
                 ("sort_threshold", C.c_uint32), ("grid_tile", C.c_uint32), ("tile_w_log2", C.c_uint32),
                 ("xcd_swizzle", C.c_uint32), ("stack_override", C.c_uint32), ("tile_order", C.c_uint32),
-                ("reserved", C.c_uint32 * 7)]
+                ("sort_key", C.c_uint32), ("reserved", C.c_uint32 * 6)]
 
 
 class Camera(C.Structure):
@@ -156,7 +156,7 @@ class Context:
 
     def __init__(self, device: int = 0, kernel: int = KERNEL_AUTO, count_visits: bool = False,
                  sort_threshold: int = 0, grid_tile: int = 0, tile_w_log2: int = 0, xcd_swizzle: int = 0,
-                 stack_override: int = 0, tile_order: int = 0):
+                 stack_override: int = 0, tile_order: int = 0, sort_key: int = 0):
         self.L = load()
         opts = Options()
         opts.struct_size = C.sizeof(Options)
@@ -168,6 +168,7 @@ class Context:
         opts.xcd_swizzle = xcd_swizzle
         opts.stack_override = stack_override
         opts.tile_order = tile_order
+        opts.sort_key = sort_key
         self.h = C.c_void_p()
         rc = self.L.mrt_create(device, C.byref(opts), C.byref(self.h))
         if rc:

@@ -20,6 +20,8 @@ namespace mrt {
 hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream);
 hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t stream);
 hipError_t launch_morton_keys(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t *keys, uint32_t *index, hipStream_t stream);
+hipError_t launch_origin_dir_keys(const void *rays, uint32_t in_fmt, uint64_t count, const float lo[3], const float hi[3],
+		uint32_t *keys, uint32_t *index, hipStream_t stream);
 hipError_t launch_detect_grid(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t tile_w_log2,
 		unsigned long long *scratch, uint32_t *out, hipStream_t stream);
 }
@@ -39,6 +41,7 @@ struct mrt_ctx {
 	// scene
 	mrt::DevNode *d_nodes = nullptr; mrt::TriHot *d_hot = nullptr; mrt::TriCold *d_cold = nullptr;
 	mrt::Dev4Node *d_nodes4 = nullptr; uint32_t n_nodes4 = 0;
+	float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
 	uint32_t n_nodes = 0, n_tris = 0, depth = 0, stack_depth = 0;
 	bool scene = false;
 	// per-dispatch buffers (grow only, x1.5: gpu_ray_caster.cpp:776-817)
@@ -141,7 +144,10 @@ int device_sort(mrt_ctx *ctx, const void *d_rays, uint32_t in_fmt, uint64_t coun
 			(rc = ensure(ctx, ctx->idx_in, count * 4)) || (rc = ensure(ctx, ctx->idx_out, count * 4))) return rc;
 	uint32_t *ki = (uint32_t *)ctx->keys_in.ptr, *ko = (uint32_t *)ctx->keys_out.ptr;
 	uint32_t *ii = (uint32_t *)ctx->idx_in.ptr, *io = (uint32_t *)ctx->idx_out.ptr;
-	HIP_TRY(ctx, mrt::launch_morton_keys(d_rays, in_fmt, count, ki, ii, ctx->stream));
+	if (ctx->opts.sort_key == 1) // the reference's direction-only key (ray_sort.h:64-76)
+		HIP_TRY(ctx, mrt::launch_morton_keys(d_rays, in_fmt, count, ki, ii, ctx->stream));
+	else // origin cell first, then direction: groups rays whose origins are scattered too
+		HIP_TRY(ctx, mrt::launch_origin_dir_keys(d_rays, in_fmt, count, ctx->bounds_lo, ctx->bounds_hi, ki, ii, ctx->stream));
 	size_t tmp_bytes = 0;
 	HIP_TRY(ctx, rocprim::radix_sort_pairs(nullptr, tmp_bytes, ki, ko, ii, io, (size_t)count, 0, 30, ctx->stream));
 	if ((rc = ensure(ctx, ctx->sort_tmp, tmp_bytes ? tmp_bytes : 16))) return rc;
@@ -335,6 +341,7 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	if (e == hipSuccess) e = hipMemcpy(ctx->d_cold, h.cold, (size_t)h.n_tris * sizeof(mrt::TriCold), hipMemcpyHostToDevice);
 	if (e == hipSuccess && want4) e = hipMemcpy(ctx->d_nodes4, h.nodes4, (size_t)h.n_nodes4 * sizeof(mrt::Dev4Node), hipMemcpyHostToDevice);
 	ctx->n_nodes4 = want4 ? h.n_nodes4 : 0;
+	for (int c = 0; c < 3; c++) { ctx->bounds_lo[c] = h.bounds_lo[c]; ctx->bounds_hi[c] = h.bounds_hi[c]; }
 	cleanup();
 	if (e != hipSuccess) { free_scene(ctx); std::snprintf(ctx->err, sizeof(ctx->err), "scene upload failed: %s", hipGetErrorString(e)); return MRT_ERR_HIP; }
 	ctx->n_nodes = h.n_nodes; ctx->n_tris = h.n_tris; ctx->depth = h.depth;

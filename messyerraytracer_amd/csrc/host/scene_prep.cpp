@@ -173,6 +173,10 @@ int prepare_scene(const mrt_tri64 *tris, uint32_t n_tris, const mrt_bvh_node32 *
 	std::memcpy(out->nodes, dev.data(), dev.size() * sizeof(DevNode));
 	out->hot = hot; out->cold = cold; out->n_tris = n_tris;
 	out->depth = depth + 1; // one pending entry per wide node on the current path + the sentinel
+	for (int c = 0; c < 3; c++) { // scene bounds = union of the root's two child boxes
+		out->bounds_lo[c] = dev[0].lmin[c] < dev[0].rmin[c] ? dev[0].lmin[c] : dev[0].rmin[c];
+		out->bounds_hi[c] = dev[0].lmax[c] > dev[0].rmax[c] ? dev[0].lmax[c] : dev[0].rmax[c];
+	}
 
 	// ---- 4-wide collapse of the same tree for the packet kernel ----
 	// Children of a 4-node: start from the two children of a BVH2 node and keep opening the

@@ -408,6 +408,49 @@ __global__ __launch_bounds__(MRT_WG) void morton_keys_kernel(const void *rays, u
 	if (index) index[g] = (uint32_t)g;
 }
 
+// ---- sort key for incoherent batches --------------------------------------------------
+// The reference sorts by direction only (ray_sort.h:64-76), which groups nothing when the
+// origins are scattered (config C4).  Results do not depend on the order, so the sort that
+// feeds the lane kernel uses origin first: 6 bits per axis of the origin inside the scene
+// bounds (Morton, 18 bits) above 4 bits per axis of the direction (Morton, 12 bits).
+// Rays that start in the same ~1/64-of-the-scene cell and point the same way share a wave.
+__global__ __launch_bounds__(MRT_WG) void origin_dir_keys_kernel(const void *rays, uint32_t in_fmt, uint64_t count,
+		float bx, float by, float bz, float sx, float sy, float sz, uint32_t *keys, uint32_t *index)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * MRT_WG + threadIdx.x;
+	if (g >= count) return;
+	float ox, oy, oz, dx, dy, dz;
+	if (in_fmt == IN_HOST60) {
+		const float *h = reinterpret_cast<const float *>(rays) + g * 15u;
+		ox = h[0]; oy = h[1]; oz = h[2]; dx = h[3]; dy = h[4]; dz = h[5];
+	} else {
+		const float4 a = reinterpret_cast<const float4 *>(rays)[g * 2u], b = reinterpret_cast<const float4 *>(rays)[g * 2u + 1u];
+		ox = a.x; oy = a.y; oz = a.z; dx = b.x; dy = b.y; dz = b.z;
+	}
+	auto q = [](float v, float lo, float scale, float top) { // clamp handles NaN / out-of-scene origins
+		const float n = fmaxf(0.0f, fminf(top, (v - lo) * scale));
+		return (uint32_t)n;
+	};
+	const uint32_t qx = q(ox, bx, sx, 63.0f), qy = q(oy, by, sy, 63.0f), qz = q(oz, bz, sz, 63.0f);
+	const uint32_t ex = q(dx, -1.0f, 8.0f, 15.0f), ey = q(dy, -1.0f, 8.0f, 15.0f), ez = q(dz, -1.0f, 8.0f, 15.0f);
+	const uint32_t ko = (spread10(qx) << 2) | (spread10(qy) << 1) | spread10(qz); // 18 bits
+	const uint32_t kd = (spread10(ex) << 2) | (spread10(ey) << 1) | spread10(ez); // 12 bits
+	keys[g] = (ko << 12) | kd;
+	if (index) index[g] = (uint32_t)g;
+}
+
+hipError_t launch_origin_dir_keys(const void *rays, uint32_t in_fmt, uint64_t count, const float lo[3], const float hi[3],
+		uint32_t *keys, uint32_t *index, hipStream_t stream)
+{
+	if (count == 0) return hipSuccess;
+	const uint64_t blocks = (count + MRT_WG - 1) / MRT_WG;
+	float s[3];
+	for (int k = 0; k < 3; k++) { const float e = hi[k] - lo[k]; s[k] = e > 0.0f ? 64.0f / e : 0.0f; }
+	hipLaunchKernelGGL(origin_dir_keys_kernel, dim3((uint32_t)blocks), dim3(MRT_WG), 0, stream, rays, in_fmt, count,
+			lo[0], lo[1], lo[2], s[0], s[1], s[2], keys, index);
+	return hipGetLastError();
+}
+
 // ---- launch wrappers (called from api.hip) -------------------------------------------
 hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream)
 {

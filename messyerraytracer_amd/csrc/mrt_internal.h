@@ -89,6 +89,7 @@ struct DeviceSceneHost {
 	DevNode *nodes = nullptr; uint32_t n_nodes = 0;
 	Dev4Node *nodes4 = nullptr; uint32_t n_nodes4 = 0;
 	uint32_t stack4 = 0;        // per-wave stack entries the 4-wide walk can need
+	float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0}; // scene AABB (sort key quantisation)
 	TriHot *hot = nullptr; TriCold *cold = nullptr; uint32_t n_tris = 0;
 	uint32_t depth = 0;         // max stack entries any traversal can need (incl. sentinel)
 };

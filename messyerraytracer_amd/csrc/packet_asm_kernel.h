@@ -26,6 +26,20 @@
 //   s36..s38 lmin.xyz  s39 left_ref | s40..s42 lmax.xyz  s43 right_ref
 //   s44..s46 rmin.xyz  s47 -        | s48..s50 rmax.xyz  s51 -
 // scratch: s52 byte offset, s53 far ref, s[54:55] right-child mask, v40..v51 slab values.
+// Optional: when a far child is pushed, touch its node with a 4-byte scalar load so the line is
+// in the scalar cache / L2 by the time it is popped (s57 is never read; a leaf ref touches node 0).
+#ifdef MRT_PREFETCH_FAR
+#define MRT_ASM_PREFETCH_FAR                                                                               \
+		"s_cmp_lt_u32 s53, 0x7fffffff\n"                                                                    \
+		"s_cselect_b32 s56, s53, 0\n"                                                                       \
+		"s_lshl_b32 s56, s56, 6\n"                                                                          \
+		"s_load_dword s57, %[base], s56\n"
+// the touch may still be in flight when the block ends; s57 is only reserved inside the block
+#define MRT_ASM_EXIT_WAIT "s_waitcnt lgkmcnt(0)\n"
+#else
+#define MRT_ASM_PREFETCH_FAR
+#define MRT_ASM_EXIT_WAIT
+#endif
 #define MRT_ASM_NODE_LOOP(LNX, LFX, LNY, LFY, LNZ, LFZ, RNX, RFX, RNY, RFY, RNZ, RFZ)                      \
 	asm volatile(                                                                                           \
 		"s_cmp_eq_u32 %[dopop], 1\n"                                                                        \
@@ -67,6 +81,7 @@
 		"v_mov_b32 v41, s53\n"                                                                              \
 		"ds_write_b32 %[sp], v41\n"                                                                         \
 		"v_add_u32 %[sp], 4, %[sp]\n"                                                                       \
+		MRT_ASM_PREFETCH_FAR                                                                                \
 		"s_branch L_check_%=\n"                                                                             \
 		"L_onlyl_%=:\n"                                                                                     \
 		"s_mov_b32 %[node], s39\n"                                                                          \
@@ -84,11 +99,12 @@
 		"L_check_%=:\n"                                                                                     \
 		"s_cmp_lt_u32 %[node], 0x7fffffff\n"                                                                \
 		"s_cbranch_scc1 L_node_%=\n"                                                                        \
+		MRT_ASM_EXIT_WAIT                                                                                   \
 		: [node] "+s"(node), [sp] "+v"(sp)                                                                  \
 		: [base] "s"(base), [dopop] "s"(dopop), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), [nrx] "v"(nrx),   \
 		  [nry] "v"(nry), [nrz] "v"(nrz), [tmin] "v"(tmin), [lim] "v"(lim)                                  \
-		: "memory", "vcc", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45",      \
-		  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "v40", "v41", "v42", "v43", \
+		: "vcc", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45",      \
+		  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "v40", "v41", "v42", "v43", \
 		  "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51")
 
 // Walks inner nodes until `node` is a leaf reference (>= 0x80000000) or the sentinel
@@ -192,7 +208,9 @@ __global__ __launch_bounds__(MRT_WG) void trace_packet_asm_kernel(const TracePar
 		packet_traverse<8, ANY_HIT, false>(p, r, stack, best_t, best_u, best_v, best_slot, nn, nt, nd);
 	} else {
 		// sentinel at the bottom of the per-wave stack; sp = LDS byte address of the next free entry
-		stack[0] = kSentinel;
+		// (volatile: the asm block has no "memory" clobber — it only reads read-only scene data and this
+		// private stack — so that the compiler keeps the triangle fetches of the leaf code scalar)
+		*(volatile uint32_t *)&stack[0] = kSentinel;
 		const uint32_t sp = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(stack + 1);
 #define MRT_PKTA(O) case O: packet_traverse_asm<O, ANY_HIT>(p, r, sp, best_t, best_u, best_v, best_slot); break;
 		switch (oct) { MRT_PKTA(0) MRT_PKTA(1) MRT_PKTA(2) MRT_PKTA(3) MRT_PKTA(4) MRT_PKTA(5) MRT_PKTA(6) MRT_PKTA(7) }

@@ -100,14 +100,15 @@ class ShardedViews:
     workload of bench.py.  Same exchange as ShardedGrid with one block per rank."""
 
     def __init__(self, width: int, rows: int, tracer: Callable[[int, int, torch.Tensor], None],
-                 device: torch.device, chunks: int = 4, group=None, gather: bool = True):
+                 device: torch.device, chunks: int = 4, group=None, gather: bool = True, force_gather: bool = False):
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.width, self.rows, self.tracer, self.group = width, rows, tracer, group
         self.row_bytes = width * HIT_BYTES
         self.chunks = chunk_bounds(0, rows, chunks)
         self.local = torch.empty(rows * self.row_bytes, dtype=torch.uint8, device=device)
-        self.gather = gather and self.world > 1
+        # force_gather: run the exchange even with one rank (rehearsal of the N > 1 path on one GPU)
+        self.gather = gather and (self.world > 1 or (force_gather and dist.is_initialized()))
         self.images = None
         if self.rank == 0 and self.gather:
             self.images = torch.empty((self.world, rows * self.row_bytes), dtype=torch.uint8, device=device)
