@@ -162,7 +162,9 @@ enum {
 	MRT_KERNEL_PACKET = 2,  /* one wave = one 64-ray packet, per-wave LDS stack, scalar fetches */
 	MRT_KERNEL_PACKET4 = 3, /* packet walk over the 4-wide collapse of the same BVH2 (128-B fetches) */
 	MRT_KERNEL_PACKET2 = 4, /* two packets per wave advanced in lockstep (two fetch chains in flight)  */
-	MRT_KERNEL_PACKET_ASM = 5 /* packet walk with the hand-written gfx950 node loop (default for coherent batches) */
+	MRT_KERNEL_PACKET_ASM = 5, /* packet walk with the hand-written gfx950 node loop (default for coherent batches) */
+	MRT_KERNEL_LANE_PERSISTENT = 6 /* lane kernel with resident waves pulling rays from a counter (default for
+	                                  large incoherent batches), short LDS stack + HBM spill               */
 };
 
 typedef struct mrt_options {
@@ -179,7 +181,8 @@ typedef struct mrt_options {
 	uint32_t tile_order;      /* 1: tiles in row-major order, 2: Z-order inside 16x16-tile super-tiles */
 	uint32_t sort_key;        /* 0: origin cell + direction Morton key (default), 1: the reference's
 	                             direction-only key (ray_sort.h:64-76); the order never changes results */
-	uint32_t reserved[6];
+	uint32_t refill;          /* persistent lane kernel: refill a wave when this many lanes are idle (default 16) */
+	uint32_t reserved[5];
 } mrt_options;
 
 typedef struct mrt_ctx mrt_ctx;

@@ -20,6 +20,8 @@ namespace mrt {
 hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream);
 hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t stream);
 hipError_t launch_morton_keys(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t *keys, uint32_t *index, hipStream_t stream);
+hipError_t launch_trace_persistent(const TraceParams &p, unsigned long long *next_ray, uint32_t *overflow,
+		uint32_t lds_depth, uint32_t refill, uint32_t blocks, bool any_hit, hipStream_t stream);
 hipError_t launch_origin_dir_keys(const void *rays, uint32_t in_fmt, uint64_t count, const float lo[3], const float hi[3],
 		uint32_t *keys, uint32_t *index, hipStream_t stream);
 hipError_t launch_detect_grid(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t tile_w_log2,
@@ -45,7 +47,8 @@ struct mrt_ctx {
 	uint32_t n_nodes = 0, n_tris = 0, depth = 0, stack_depth = 0;
 	bool scene = false;
 	// per-dispatch buffers (grow only, x1.5: gpu_ray_caster.cpp:776-817)
-	DevBuf rays, hits, keys_in, keys_out, idx_in, idx_out, sort_tmp;
+	DevBuf rays, hits, keys_in, keys_out, idx_in, idx_out, sort_tmp, overflow;
+	int cu_count = 256;
 	unsigned long long *d_counters = nullptr;
 	// async state
 	bool pending = false;
@@ -120,9 +123,7 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 // primary-ray grids), one lane per ray for everything else (sorted / incoherent batches).
 uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent)
 {
-	if (ctx->opts.kernel == MRT_KERNEL_LANE || ctx->opts.kernel == MRT_KERNEL_PACKET || ctx->opts.kernel == MRT_KERNEL_PACKET4 ||
-			ctx->opts.kernel == MRT_KERNEL_PACKET2 || ctx->opts.kernel == MRT_KERNEL_PACKET_ASM)
-		return ctx->opts.kernel;
+	if (ctx->opts.kernel >= MRT_KERNEL_LANE && ctx->opts.kernel <= MRT_KERNEL_LANE_PERSISTENT) return ctx->opts.kernel;
 	// (PACKET4 halves the fetch chain but measured 7 % slower at C3: the walk is bound by
 	// instruction issue, and ordering four children costs more scalar work than it saves)
 	// PACKET_ASM: same walk with the hand-written node loop (the compiler's loop is scalar-ALU bound)
@@ -197,15 +198,39 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	// Coherent batch without a declared width: look for the row width on the device and let the
 	// trace kernel tile its lanes (no host round trip: the kernel reads the answer from HBM).
 	// Timed with the sort as pre-processing (last_sort_ms); last_trace_ms is the trace kernel alone.
-	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 4096 && ctx->opts.grid_tile != 1;
+	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 4096 && ctx->opts.grid_tile != 1 &&
+			p.kernel != MRT_KERNEL_LANE_PERSISTENT;
 	if (detect) {
 		uint32_t *d_auto = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);
 		HIP_TRY(ctx, mrt::launch_detect_grid(d_rays, p.in_fmt, count, p.tile_w_log2, ctx->d_counters + 16, d_auto, ctx->stream));
 		p.lane_map = mrt::MAP_AUTO; p.auto_grid = d_auto;
 	}
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
-	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
+	// Large incoherent batches: resident waves that pull rays from a counter (no counting variant).
+	const bool persistent = !ctx->opts.count_visits && p.lane_map == mrt::MAP_LINEAR &&
+			(p.kernel == MRT_KERNEL_LANE_PERSISTENT || (ctx->opts.kernel == MRT_KERNEL_AUTO && p.kernel == MRT_KERNEL_LANE && count >= 65536));
+	if (persistent) {
+		const uint32_t lds_depth = ctx->opts.stack_override >= 4 && ctx->opts.stack_override <= 64 ? ctx->opts.stack_override : 16u;
+		const uint32_t lds_bytes = 4u * lds_depth * 64u * 4u; // per 256-thread workgroup
+		uint32_t wg_per_cu = (160u * 1024u) / lds_bytes; if (wg_per_cu > 8u) wg_per_cu = 8u;
+		uint64_t blocks = (uint64_t)ctx->cu_count * wg_per_cu;
+		const uint64_t needed = (count + 255u) / 256u;
+		if (blocks > needed) blocks = needed;
+		uint32_t *ovf = nullptr;
+		if (ctx->depth > lds_depth) { // deeper entries spill to [depth - lds_depth][thread] in HBM
+			if ((rc = ensure(ctx, ctx->overflow, (size_t)(ctx->depth - lds_depth) * blocks * 256u * 4u))) return rc;
+			ovf = (uint32_t *)ctx->overflow.ptr;
+		}
+		unsigned long long *next_ray = ctx->d_counters + 12;
+		HIP_TRY(ctx, hipMemsetAsync(next_ray, 0, sizeof(unsigned long long), ctx->stream));
+		HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+		HIP_TRY(ctx, mrt::launch_trace_persistent(p, next_ray, ovf, lds_depth, ctx->opts.refill ? ctx->opts.refill : 16u,
+				(uint32_t)blocks, mode == MRT_MODE_ANY_HIT, ctx->stream));
+	} else {
+		if (p.kernel == MRT_KERNEL_LANE_PERSISTENT) p.kernel = MRT_KERNEL_LANE;
+		HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+		HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
+	}
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
 	ctx->stats.last_kernel_launches = sort ? 3 : (detect ? 2 : 1);
 	ctx->stats.rays_cast += count;
@@ -273,6 +298,10 @@ int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
 	auto bail = [&](int code) { mrt_destroy(ctx); return code; };
 	if (hipSetDevice(device_ordinal) != hipSuccess) return bail(MRT_ERR_NO_DEVICE);
 	if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) return bail(MRT_ERR_HIP);
+	{
+		int cus = 0;
+		if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0) ctx->cu_count = cus;
+	}
 	ctx->stream = ctx->own_stream;
 	for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) return bail(MRT_ERR_HIP);
 	// [0..7] visit counters, [8..15] detected grid, [16..1040] detect_grid_kernel scratch (masks + ticket)
@@ -289,7 +318,7 @@ void mrt_destroy(mrt_ctx *ctx)
 	if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
 	free_scene(ctx);
 	release(ctx->rays); release(ctx->hits); release(ctx->keys_in); release(ctx->keys_out);
-	release(ctx->idx_in); release(ctx->idx_out); release(ctx->sort_tmp);
+	release(ctx->idx_in); release(ctx->idx_out); release(ctx->sort_tmp); release(ctx->overflow);
 	if (ctx->d_counters) (void)hipFree(ctx->d_counters);
 	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);

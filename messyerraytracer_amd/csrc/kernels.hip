@@ -268,6 +268,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 	}
 }
 
+#include "lane_persistent_kernel.h"
 #include "packet_kernel.h"
 #include "packet4_kernel.h"
 #include "packet2_kernel.h"
@@ -510,6 +511,20 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		if (count) hipLaunchKernelGGL((trace_lane_kernel<false, true>), grid, wg, lds, stream, p);
 		else hipLaunchKernelGGL((trace_lane_kernel<false, false>), grid, wg, lds, stream, p);
 	}
+	return hipGetLastError();
+}
+
+// Persistent lane kernel: `blocks` workgroups stay resident and pull rays from *next_ray.
+hipError_t launch_trace_persistent(const TraceParams &p, unsigned long long *next_ray, uint32_t *overflow,
+		uint32_t lds_depth, uint32_t refill, uint32_t blocks, bool any_hit, hipStream_t stream)
+{
+	if (p.count == 0 || blocks == 0) return hipSuccess;
+	PersistParams q;
+	q.next_ray = next_ray; q.overflow = overflow; q.overflow_stride = blocks * MRT_WG;
+	q.lds_depth = lds_depth; q.refill = refill;
+	const size_t lds = (size_t)(MRT_WG / MRT_WAVE) * lds_depth * MRT_WAVE * sizeof(uint32_t);
+	if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+	else hipLaunchKernelGGL((trace_lane_persistent_kernel<false>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
 	return hipGetLastError();
 }
 

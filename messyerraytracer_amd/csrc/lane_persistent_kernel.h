@@ -1,0 +1,166 @@
+// lane_persistent_kernel.h — one lane = one ray, persistent waves with ray refill.
+// Included by kernels.hip (inside namespace mrt, after the common helpers).
+//
+// For incoherent batches (config C4).  profiles/r01_c4lane: with one fixed ray per lane a
+// wave executes ~540 loop iterations for rays that need ~89 (16 % SIMD efficiency: the
+// wave runs until its slowest ray ends) at 5 waves per SIMD (LDS stack), 74 % of the time
+// waiting on the divergent node fetches.  This kernel
+//   * keeps the grid resident (waves x CUs that fit) and lets every wave pull rays from
+//     one global counter: when at least `refill` lanes have finished, the wave stores
+//     their hits and hands them new rays (ballot + mbcnt prefix, one atomicAdd per refill);
+//   * keeps only the top `lds_depth` stack entries per lane in LDS ([depth][lane] layout)
+//     and spills deeper entries to a per-lane slice of an HBM scratch buffer, so LDS no
+//     longer limits occupancy (16 entries = 4 KB per wave -> 8 waves per SIMD).
+// The traversal itself is trace_lane_kernel's (same arithmetic, same tie rule).
+#pragma once
+
+struct PersistParams {
+	unsigned long long *next_ray; // global ray counter (zeroed before the launch)
+	uint32_t *overflow;           // [depth - lds_depth][global thread] spill area
+	uint32_t overflow_stride;     // = total threads of the launch
+	uint32_t lds_depth;           // stack entries per lane kept in LDS
+	uint32_t refill;              // refill when at least this many lanes are idle
+};
+
+template <bool ANY_HIT>
+__global__ __launch_bounds__(MRT_WG) void trace_lane_persistent_kernel(const TraceParams p, const PersistParams q)
+{
+	extern __shared__ uint32_t lds_stack[];
+	const uint32_t lane = threadIdx.x & (MRT_WAVE - 1), wave = threadIdx.x / MRT_WAVE;
+	const uint32_t gtid = blockIdx.x * MRT_WG + threadIdx.x;
+	const uint32_t lds_base = wave * (q.lds_depth * MRT_WAVE) + lane;
+	const float4 *nodes = reinterpret_cast<const float4 *>(p.nodes);
+	const float4 *hot = reinterpret_cast<const float4 *>(p.tri_hot);
+
+	// per-lane ray state
+	RayRegs r = {};
+	uint64_t ray_idx = 0;
+	float ix = 0, iy = 0, iz = 0, nrx = 0, nry = 0, nrz = 0;
+	float best_t = 0, best_u = 0, best_v = 0;
+	uint32_t best_slot = 0xFFFFFFFFu, best_id = 0xFFFFFFFFu;
+	uint32_t cur = kSentinel; // kSentinel = this lane has no work
+	uint32_t depth = 0;
+	bool has_ray = false;
+	bool exhausted = false;   // wave-uniform: the ray counter ran past the batch
+
+	auto push = [&](uint32_t ref) {
+		if (depth < q.lds_depth) lds_stack[lds_base + depth * MRT_WAVE] = ref;
+		else q.overflow[(size_t)(depth - q.lds_depth) * q.overflow_stride + gtid] = ref;
+		depth++;
+	};
+	auto pop = [&]() -> uint32_t {
+		if (depth == 0) return kSentinel;
+		depth--;
+		return depth < q.lds_depth ? lds_stack[lds_base + depth * MRT_WAVE]
+		                           : q.overflow[(size_t)(depth - q.lds_depth) * q.overflow_stride + gtid];
+	};
+
+	for (;;) {
+		// ---- retire finished lanes, hand out new rays ----
+		const bool idle = cur == kSentinel;
+		if (idle && has_ray) {
+			int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
+			if (best_slot != 0xFFFFFFFFu) {
+				prim = (int32_t)p.tri_hot[best_slot].id;
+				layers = p.tri_hot[best_slot].layers;
+				const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
+				nx = nn.x; ny = nn.y; nz = nn.z;
+			}
+			store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers);
+			has_ray = false;
+		}
+		const unsigned long long idle_mask = __ballot(idle);
+		if (!exhausted && idle_mask != 0ull) {
+			const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle_mask);
+			unsigned long long base = 0;
+			if (lane == (uint32_t)__builtin_ctzll(idle_mask)) base = atomicAdd(q.next_ray, (unsigned long long)n_idle);
+			base = __shfl(base, __builtin_ctzll(idle_mask));
+			if (base + n_idle >= p.count) exhausted = true; // the counter only grows: nothing left after this hand-out
+			if (idle) {
+				const uint32_t rank = (uint32_t)__builtin_popcountll(idle_mask & ((1ull << lane) - 1ull));
+				const uint64_t g = base + rank;
+				if (g < p.count) {
+					ray_idx = p.perm ? (uint64_t)p.perm[g] : g;
+					load_ray(p, ray_idx, 0, 0, r);
+					has_ray = true;
+					best_t = r.t_max; best_u = 0.0f; best_v = 0.0f; best_slot = 0xFFFFFFFFu; best_id = 0xFFFFFFFFu;
+					depth = 0;
+					if (r.t_min >= r.t_max) cur = kSentinel; // degenerate: a miss, retired on the next round
+					else {
+						ix = safe_inv(r.dx); iy = safe_inv(r.dy); iz = safe_inv(r.dz);
+						nrx = -(r.ox * ix); nry = -(r.oy * iy); nrz = -(r.oz * iz);
+						cur = 0;
+					}
+				}
+			}
+		}
+		if (__ballot(has_ray) == 0ull) break; // no lane holds a ray and none is left to fetch
+
+		// ---- traverse until enough lanes have finished to make a refill worthwhile ----
+		for (;;) {
+			while (cur < kSentinel) { // inner nodes: glsl:243-318
+				const float4 *n = nodes + (size_t)cur * 4u;
+				const float4 a = n[0], b = n[1], c = n[2], d = n[3];
+				const float l0x = fma_(a.x, ix, nrx), l1x = fma_(b.x, ix, nrx);
+				const float l0y = fma_(a.y, iy, nry), l1y = fma_(b.y, iy, nry);
+				const float l0z = fma_(a.z, iz, nrz), l1z = fma_(b.z, iz, nrz);
+				const float r0x = fma_(c.x, ix, nrx), r1x = fma_(d.x, ix, nrx);
+				const float r0y = fma_(c.y, iy, nry), r1y = fma_(d.y, iy, nry);
+				const float r0z = fma_(c.z, iz, nrz), r1z = fma_(d.z, iz, nrz);
+				const float tl = fmaxf(fmaxf(fminf(l0x, l1x), fminf(l0y, l1y)), fmaxf(fminf(l0z, l1z), r.t_min));
+				const float tlx = fminf(fminf(fmaxf(l0x, l1x), fmaxf(l0y, l1y)), fminf(fmaxf(l0z, l1z), best_t));
+				const float tr = fmaxf(fmaxf(fminf(r0x, r1x), fminf(r0y, r1y)), fmaxf(fminf(r0z, r1z), r.t_min));
+				const float trx = fminf(fminf(fmaxf(r0x, r1x), fmaxf(r0y, r1y)), fminf(fmaxf(r0z, r1z), best_t));
+				const bool hl = tl <= tlx, hr = tr <= trx;
+				const uint32_t lref = __float_as_uint(a.w), rref = __float_as_uint(b.w);
+				if (hl && hr) {
+					const bool left_near = tl < tr;
+					push(left_near ? rref : lref);
+					cur = left_near ? lref : rref;
+				} else if (hl) cur = lref;
+				else if (hr) cur = rref;
+				else cur = pop();
+			}
+			while (cur >= kLeafBit) { // leaves: glsl:166-192
+				uint32_t slot = cur & 0x7FFFFFFFu;
+				bool last;
+				do {
+					const float4 *t3 = hot + (size_t)slot * 3u;
+					const float4 q0 = t3[0], q1 = t3[1], q2 = t3[2];
+					last = (__float_as_uint(q2.w) & kLastInLeaf) != 0u;
+					if ((__float_as_uint(q1.w) & p.query_mask) != 0u) {
+						const float pvx = fma_(r.dy, q2.z, -(r.dz * q2.y));
+						const float pvy = fma_(r.dz, q2.x, -(r.dx * q2.z));
+						const float pvz = fma_(r.dx, q2.y, -(r.dy * q2.x));
+						const float det = dot3(q1.x, q1.y, q1.z, pvx, pvy, pvz);
+						if (!(__builtin_fabsf(det) < 1e-8f)) {
+							const float inv_det = 1.0f / det;
+							const float tvx = r.ox - q0.x, tvy = r.oy - q0.y, tvz = r.oz - q0.z;
+							const float u = dot3(tvx, tvy, tvz, pvx, pvy, pvz) * inv_det;
+							if (!(u < 0.0f || u > 1.0f)) {
+								const float qvx = fma_(tvy, q1.z, -(tvz * q1.y));
+								const float qvy = fma_(tvz, q1.x, -(tvx * q1.z));
+								const float qvz = fma_(tvx, q1.y, -(tvy * q1.x));
+								const float v = dot3(r.dx, r.dy, r.dz, qvx, qvy, qvz) * inv_det;
+								if (!(v < 0.0f || u + v > 1.0f)) {
+									const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
+									const uint32_t id = __float_as_uint(q0.w);
+									if (!(t < r.t_min) && (t < best_t || (t == best_t && best_slot != 0xFFFFFFFFu && id < best_id))) {
+										best_t = t; best_u = u; best_v = v; best_slot = slot; best_id = id;
+										if (ANY_HIT) last = true;
+									}
+								}
+							}
+						}
+					}
+					slot++;
+				} while (!last);
+				if (ANY_HIT && best_slot != 0xFFFFFFFFu) { cur = kSentinel; depth = 0; break; }
+				cur = pop();
+			}
+			const unsigned long long busy = __ballot(cur != kSentinel);
+			if (busy == 0ull) break;
+			if (!exhausted && (uint32_t)__builtin_popcountll(busy) + q.refill <= MRT_WAVE) break; // enough idle lanes: refill
+		}
+	}
+}

@@ -294,6 +294,26 @@ def test_counting_variant_matches_oracle_counters(built):
     c.close()
 
 
+@pytest.mark.parametrize("lds_depth,refill", [(4, 16), (8, 1), (16, 64), (64, 16)])
+def test_persistent_lane_kernel_spill_and_refill(built, lds_depth, refill):
+    """Resident waves pulling rays from a counter; stack entries beyond `lds_depth` spill to HBM.
+    A 4-entry LDS stack forces the spill path on almost every ray."""
+    c = capi.Context(0, kernel=capi.KERNEL_LANE_PERSISTENT, stack_override=lds_depth, refill=refill)
+    v = synth.soup(20000, 0.25, 33)
+    scene, osc = capi.Scene(v), po.OracleScene(v)
+    scene.upload(c)
+    assert c.scene_info()["stack_need"] > 8
+    for n in (1, 100, 70001, 300000):
+        rays = synth.incoherent_rays(n, 41 + n)
+        rays["t_max"][::7] = 2.0
+        want = osc.trace(rays)
+        parity.assert_exact(c.cast(rays, flags=capi.FLAG_COHERENT), want, f"persistent n={n} unsorted")
+        parity.assert_exact(c.cast(rays), want, f"persistent n={n} sorted")
+        b = c.cast(rays, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT)
+        assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
+    c.close()
+
+
 def test_row_width_detection_for_coherent_batches(built):
     """mrt_cast(COHERENT) gets no image width (the reference's cast_rays has none): the
     device looks for it.  Whatever it finds, the results are the oracle's."""
@@ -326,7 +346,7 @@ def test_row_width_detection_for_coherent_batches(built):
 
 
 @pytest.mark.parametrize("kernel", [capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET4, capi.KERNEL_PACKET2,
-                                    capi.KERNEL_PACKET_ASM])
+                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_LANE_PERSISTENT])
 def test_both_kernels_on_every_kind_of_batch(built, kernel):
     """Either kernel must give the oracle's answer for any batch, coherent or not:
     the kernel choice (MRT_KERNEL_AUTO) is a speed decision only."""
@@ -404,6 +424,17 @@ def _full_grid_case(ctx, name, oracle_rows):
 def test_c2_full(ctx):
     """Config C2: 100 k-triangle soup, 1024^2 primary rays."""
     _full_grid_case(ctx, "C2", (448, 576))
+    # the same batch as HOST arrays (the reference's cast_rays contract): must equal the device-resident cast
+    cfg = synth.CONFIGS["C2"]
+    w, h = cfg["grid"]
+    cam = capi.camera_look(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
+    want = ctx.cast_grid(cam, w, h)
+    rays = po.grid_rays(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
+    got = ctx.cast(rays, flags=capi.FLAG_COHERENT)
+    assert got.tobytes() == want.tobytes()
+    host = po.make_host_rays(rays)
+    got44 = ctx.cast(host, flags=capi.FLAG_COHERENT | capi.FLAG_HOST_LAYOUT)
+    assert got44.tobytes() == po.unpack_hits(want, host).tobytes()
 
 
 def test_c3_full_headline(ctx):

@@ -59,9 +59,15 @@ def incoherent_case(name, rounds, out):
     n = rays.shape[0]
     r = dict(rays=n, tris=int(scene.tris.shape[0]))
     dev = capi.FLAG_RAYS_ON_DEVICE | capi.FLAG_HITS_ON_DEVICE
-    for kname, kern, skey in (("lane", capi.KERNEL_LANE, 0), ("lane_dirkey", capi.KERNEL_LANE, 1),
-                              ("packet_asm", capi.KERNEL_PACKET_ASM, 0)):
-        ctx = capi.Context(0, kernel=kern, sort_key=skey)
+    variants = [("lane", dict(kernel=capi.KERNEL_LANE)), ("lane_dirkey", dict(kernel=capi.KERNEL_LANE, sort_key=1)),
+                ("persist16", dict(kernel=capi.KERNEL_LANE_PERSISTENT)),
+                ("persist16_r8", dict(kernel=capi.KERNEL_LANE_PERSISTENT, refill=8)),
+                ("persist16_r32", dict(kernel=capi.KERNEL_LANE_PERSISTENT, refill=32)),
+                ("persist24", dict(kernel=capi.KERNEL_LANE_PERSISTENT, stack_override=24)),
+                ("persist32", dict(kernel=capi.KERNEL_LANE_PERSISTENT, stack_override=32)),
+                ("auto", dict())]
+    for kname, kw in variants:
+        ctx = capi.Context(0, **kw)
         scene.upload(ctx)
         d_rays, d_hits = ctx.device_alloc(n * 32), ctx.device_alloc(n * 32)
         ctx.h2d(d_rays, rays)
