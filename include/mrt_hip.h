@@ -137,7 +137,7 @@ typedef struct mrt_stats {
 	uint32_t max_stack_depth;    /* count_visits only                           */
 	uint64_t dead_pops;          /* count_visits, packet kernel: popped nodes no lane still needed */
 	uint32_t detected_grid_w;    /* count_visits: row width found for the last coherent mrt_cast (0 = none) */
-	uint32_t reserved;
+	uint32_t reserved;           /* count_visits: 1 if the last batch declared coherent was judged incoherent on the device */
 } mrt_stats;
 
 /* mode: RayQuery::Mode, src/api/ray_query.h:54-57 / RAY_MODE spec constant,

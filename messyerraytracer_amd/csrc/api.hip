@@ -157,6 +157,34 @@ int device_sort(mrt_ctx *ctx, const void *d_rays, uint32_t in_fmt, uint64_t coun
 	return MRT_OK;
 }
 
+// Lane kernel launch: plain (one fixed ray per lane) or persistent (resident waves pulling rays
+// from a counter, short LDS stack with HBM spill).
+int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit, bool persistent)
+{
+	int rc;
+	if (!persistent || ctx->opts.count_visits) {
+		p.kernel = MRT_KERNEL_LANE;
+		HIP_TRY(ctx, mrt::launch_trace(p, any_hit, ctx->opts.count_visits != 0, ctx->stream));
+		return MRT_OK;
+	}
+	const uint32_t lds_depth = ctx->opts.stack_override >= 4 && ctx->opts.stack_override <= 64 ? ctx->opts.stack_override : 16u;
+	const uint32_t lds_bytes = 4u * lds_depth * 64u * 4u; // per 256-thread workgroup
+	uint32_t wg_per_cu = (160u * 1024u) / lds_bytes; if (wg_per_cu > 8u) wg_per_cu = 8u;
+	uint64_t blocks = (uint64_t)ctx->cu_count * wg_per_cu;
+	const uint64_t needed = (count + 255u) / 256u;
+	if (blocks > needed) blocks = needed;
+	uint32_t *ovf = nullptr;
+	if (ctx->depth > lds_depth) { // deeper entries spill to [depth - lds_depth][thread] in HBM
+		if ((rc = ensure(ctx, ctx->overflow, (size_t)(ctx->depth - lds_depth) * blocks * 256u * 4u))) return rc;
+		ovf = (uint32_t *)ctx->overflow.ptr;
+	}
+	unsigned long long *next_ray = ctx->d_counters + 12;
+	HIP_TRY(ctx, hipMemsetAsync(next_ray, 0, sizeof(unsigned long long), ctx->stream));
+	HIP_TRY(ctx, mrt::launch_trace_persistent(p, next_ray, ovf, lds_depth, ctx->opts.refill ? ctx->opts.refill : 16u,
+			(uint32_t)blocks, any_hit, ctx->stream));
+	return MRT_OK;
+}
+
 // Enqueue H2D (if needed) + optional sort + trace.  On return the kernels are queued on ctx->stream.
 int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_t count, uint32_t query_mask,
 		int mode, uint32_t flags, void **d_hits_out)
@@ -206,30 +234,23 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 		p.lane_map = mrt::MAP_AUTO; p.auto_grid = d_auto;
 	}
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
-	// Large incoherent batches: resident waves that pull rays from a counter (no counting variant).
-	const bool persistent = !ctx->opts.count_visits && p.lane_map == mrt::MAP_LINEAR &&
-			(p.kernel == MRT_KERNEL_LANE_PERSISTENT || (ctx->opts.kernel == MRT_KERNEL_AUTO && p.kernel == MRT_KERNEL_LANE && count >= 65536));
-	if (persistent) {
-		const uint32_t lds_depth = ctx->opts.stack_override >= 4 && ctx->opts.stack_override <= 64 ? ctx->opts.stack_override : 16u;
-		const uint32_t lds_bytes = 4u * lds_depth * 64u * 4u; // per 256-thread workgroup
-		uint32_t wg_per_cu = (160u * 1024u) / lds_bytes; if (wg_per_cu > 8u) wg_per_cu = 8u;
-		uint64_t blocks = (uint64_t)ctx->cu_count * wg_per_cu;
-		const uint64_t needed = (count + 255u) / 256u;
-		if (blocks > needed) blocks = needed;
-		uint32_t *ovf = nullptr;
-		if (ctx->depth > lds_depth) { // deeper entries spill to [depth - lds_depth][thread] in HBM
-			if ((rc = ensure(ctx, ctx->overflow, (size_t)(ctx->depth - lds_depth) * blocks * 256u * 4u))) return rc;
-			ovf = (uint32_t *)ctx->overflow.ptr;
-		}
-		unsigned long long *next_ray = ctx->d_counters + 12;
-		HIP_TRY(ctx, hipMemsetAsync(next_ray, 0, sizeof(unsigned long long), ctx->stream));
-		HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-		HIP_TRY(ctx, mrt::launch_trace_persistent(p, next_ray, ovf, lds_depth, ctx->opts.refill ? ctx->opts.refill : 16u,
-				(uint32_t)blocks, mode == MRT_MODE_ANY_HIT, ctx->stream));
+	const bool any = mode == MRT_MODE_ANY_HIT;
+	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+	if (detect && ctx->opts.kernel == MRT_KERNEL_AUTO && !ctx->opts.count_visits) {
+		// The caller said "coherent"; the device checks.  Packet launch first, lane launch behind it:
+		// detect_grid_kernel's verdict (d_auto[3]) makes exactly one of them do the work.
+		p.skip_flag = p.auto_grid + 3; p.skip_when = 1u;
+		HIP_TRY(ctx, mrt::launch_trace(p, any, false, ctx->stream));
+		mrt::TraceParams lp = p;
+		lp.kernel = MRT_KERNEL_LANE; lp.lane_map = mrt::MAP_LINEAR; lp.auto_grid = nullptr; lp.skip_when = 0u;
+		if ((rc = launch_lane(ctx, lp, count, any, count >= 65536))) return rc;
 	} else {
-		if (p.kernel == MRT_KERNEL_LANE_PERSISTENT) p.kernel = MRT_KERNEL_LANE;
-		HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-		HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
+		// large incoherent batches: resident waves that pull rays from a counter (no counting variant)
+		const bool persistent = !ctx->opts.count_visits && p.lane_map == mrt::MAP_LINEAR &&
+				(p.kernel == MRT_KERNEL_LANE_PERSISTENT || (ctx->opts.kernel == MRT_KERNEL_AUTO && p.kernel == MRT_KERNEL_LANE && count >= 65536));
+		if (p.kernel == MRT_KERNEL_LANE_PERSISTENT || p.kernel == MRT_KERNEL_LANE) {
+			if ((rc = launch_lane(ctx, p, count, any, persistent))) return rc;
+		} else HIP_TRY(ctx, mrt::launch_trace(p, any, ctx->opts.count_visits != 0, ctx->stream));
 	}
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
 	ctx->stats.last_kernel_launches = sort ? 3 : (detect ? 2 : 1);
@@ -254,6 +275,7 @@ int finish_timing(mrt_ctx *ctx, bool h2d, bool sorted, bool d2h)
 		uint32_t g[4] = {0, 0, 0, 0};
 		if (ctx->stats.last_kernel_launches == 2) HIP_TRY(ctx, hipMemcpy(g, ctx->d_counters + 8, sizeof(g), hipMemcpyDeviceToHost));
 		ctx->stats.detected_grid_w = g[0];
+		ctx->stats.reserved = g[3]; // 1: the "coherent" batch was judged incoherent (lane kernel takes it)
 	}
 	return MRT_OK;
 }
@@ -305,8 +327,8 @@ int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
 	ctx->stream = ctx->own_stream;
 	for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) return bail(MRT_ERR_HIP);
 	// [0..7] visit counters, [8..15] detected grid, [16..1040] detect_grid_kernel scratch (masks + ticket)
-	if (hipMalloc(&ctx->d_counters, (16 + 1025) * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_OOM);
-	if (hipMemset(ctx->d_counters, 0, (16 + 1025) * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_HIP);
+	if (hipMalloc(&ctx->d_counters, (16 + 1026) * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_OOM);
+	if (hipMemset(ctx->d_counters, 0, (16 + 1026) * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_HIP);
 	*out = ctx;
 	return MRT_OK;
 }

@@ -37,6 +37,14 @@ struct RayRegs {
 	float ox, oy, oz, dx, dy, dz, t_min, t_max;
 };
 
+// Two launches are queued for a batch declared coherent: the packet kernel and, behind it, the
+// lane kernel.  detect_grid_kernel decides on the device which one does the work; the other
+// returns here (a few microseconds for an empty grid, no host round trip).
+__device__ __forceinline__ bool skip_launch(const TraceParams &p)
+{
+	return p.skip_flag != nullptr && *p.skip_flag == p.skip_when;
+}
+
 // ---- lane -> ray mapping ---------------------------------------------------------
 // MAP_LINEAR: thread g traces ray g (or perm[g]).  MAP_TILE8X8: a wave owns an
 // 8x8 pixel tile of the row-major grid so its 64 rays share most of their path.
@@ -151,6 +159,7 @@ template <bool ANY_HIT, bool COUNT>
 __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 {
 	extern __shared__ uint32_t lds_stack[];
+	if (skip_launch(p)) return;
 	uint32_t block = blockIdx.x;
 	if (p.xcd_swizzle) { // contiguous band of the batch per XCD (blocks are dealt round-robin over 8 XCDs)
 		const uint32_t per = gridDim.x >> 3;
@@ -321,14 +330,20 @@ __global__ __launch_bounds__(MRT_DETECT_THREADS) void detect_grid_kernel(const v
 	const float thr = 36.0f * step2; // a jump of more than 6 pixel steps
 	// phase 1: every thread looks at one pair (i-1, i); one 64-bit jump mask per wave
 	const uint32_t i = blockIdx.x * MRT_DETECT_THREADS + threadIdx.x;
-	bool jump = false;
+	bool jump = false, wide = false;
 	if (i >= 1 && i < m) {
 		ray_dir(rays, in_fmt, i - 1, ax, ay, az);
 		ray_dir(rays, in_fmt, i, bx, by, bz);
-		jump = (bx - ax) * (bx - ax) + (by - ay) * (by - ay) + (bz - az) * (bz - az) > thr;
+		const float d2 = (bx - ax) * (bx - ax) + (by - ay) * (by - ay) + (bz - az) * (bz - az);
+		jump = d2 > thr;
+		wide = !(d2 <= 0.01f); // neighbours more than ~6 degrees apart (or NaN): not what a packet wants
 	}
 	const unsigned long long mask = __ballot(jump);
-	if ((threadIdx.x & 63u) == 0u) __hip_atomic_store(&scratch[i >> 6], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	const unsigned long long wmask_dir = __ballot(wide);
+	if ((threadIdx.x & 63u) == 0u) {
+		__hip_atomic_store(&scratch[i >> 6], mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		if (wmask_dir) atomicAdd(&scratch[1025], (unsigned long long)__builtin_popcountll(wmask_dir));
+	}
 	// hand-off to the block that finishes last (agent-scope release / acquire, guide G16)
 	__threadfence();
 	__syncthreads();
@@ -363,7 +378,11 @@ __global__ __launch_bounds__(MRT_DETECT_THREADS) void detect_grid_kernel(const v
 			rows = (uint32_t)r; tiles_x = w >> tile_w_log2;
 		}
 		out[0] = ok ? w : 0u; out[1] = ok ? rows : 0u; out[2] = ok ? tiles_x : 0u;
-		scratch[1024] = 0ull; // ticket for the next launch (stream ordered)
+		// "coherent" was only the caller's word: if more than 1 in 8 neighbouring rays point
+		// somewhere else, the batch goes to the lane kernel (out[3] = 1) instead of packets
+		const unsigned long long n_wide = __hip_atomic_load(&scratch[1025], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		out[3] = (n_wide * 8ull > (unsigned long long)m) ? 1u : 0u;
+		scratch[1024] = 0ull; scratch[1025] = 0ull; // ticket / counter for the next launch (stream ordered)
 	}
 }
 

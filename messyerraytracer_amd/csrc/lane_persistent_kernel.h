@@ -26,6 +26,7 @@ template <bool ANY_HIT>
 __global__ __launch_bounds__(MRT_WG) void trace_lane_persistent_kernel(const TraceParams p, const PersistParams q)
 {
 	extern __shared__ uint32_t lds_stack[];
+	if (skip_launch(p)) return;
 	const uint32_t lane = threadIdx.x & (MRT_WAVE - 1), wave = threadIdx.x / MRT_WAVE;
 	const uint32_t gtid = blockIdx.x * MRT_WG + threadIdx.x;
 	const uint32_t lds_base = wave * (q.lds_depth * MRT_WAVE) + lane;

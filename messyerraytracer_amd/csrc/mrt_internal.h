@@ -70,7 +70,9 @@ struct TraceParams {
 	void *hits;                // device
 	const uint32_t *perm;      // optional: lane g traces ray perm[g], writes hits[perm[g]]
 	unsigned long long *counters; // COUNT variants: rays, tri_tests, node_visits, hits, max_stack
-	const uint32_t *auto_grid; // MAP_AUTO: {row width (0 = none), rows, tiles_x} written by detect_grid_kernel
+	const uint32_t *auto_grid; // MAP_AUTO: {row width (0 = none), rows, tiles_x, incoherent} written by detect_grid_kernel
+	const uint32_t *skip_flag; // optional: the whole launch returns at once when *skip_flag == skip_when
+	uint32_t skip_when;        // (a "coherent" batch that is not: the packet launch yields to the lane launch)
 	uint64_t count;            // number of rays
 	uint32_t query_mask;
 	uint32_t in_fmt, out_fmt, lane_map;

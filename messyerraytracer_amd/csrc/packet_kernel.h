@@ -132,6 +132,7 @@ template <bool ANY_HIT, bool COUNT>
 __global__ __launch_bounds__(MRT_WG) void trace_packet_kernel(const TraceParams p)
 {
 	__shared__ uint32_t wave_stack[MRT_WG / MRT_WAVE][MRT_PACKET_STACK];
+	if (skip_launch(p)) return;
 	uint32_t block = blockIdx.x;
 	if (p.xcd_swizzle) {
 		const uint32_t per = gridDim.x >> 3;

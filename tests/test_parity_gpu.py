@@ -318,9 +318,11 @@ def test_row_width_detection_for_coherent_batches(built):
     """mrt_cast(COHERENT) gets no image width (the reference's cast_rays has none): the
     device looks for it.  Whatever it finds, the results are the oracle's."""
     c = capi.Context(0, count_visits=True)
+    c_auto = capi.Context(0)
     v = synth.soup(5000, 0.3, 29)
     scene, osc = capi.Scene(v), po.OracleScene(v)
     scene.upload(c)
+    scene.upload(c_auto)
     cases = []
     for (w, h, expect) in ((128, 64, 128), (256, 40, 256), (64, 64, 64), (100, 64, 0), (128, 60, 0), (24, 200, 24)):
         cases.append((po.grid_rays((0, 0, -12), (0, 0, 1), w, h, 50.0), expect, f"{w}x{h}"))
@@ -328,6 +330,7 @@ def test_row_width_detection_for_coherent_batches(built):
     b = po.grid_rays((0, 0, -12), (0, 0, 1), 64, 64, 50.0)
     cases.append((np.concatenate([a, b]), None, "two grids glued"))   # width changes half way: any answer is fine
     cases.append((synth.incoherent_rays(8192, 3), 0, "incoherent rays declared coherent"))
+    cases.append((synth.incoherent_rays(100000, 5), 0, "incoherent rays declared coherent, large batch"))
     same = po.grid_rays((0, 0, -12), (0, 0, 1), 64, 64, 50.0)
     same["direction"][:] = same["direction"][0]
     cases.append((same, 0, "identical directions"))
@@ -339,6 +342,9 @@ def test_row_width_detection_for_coherent_batches(built):
         assert s["last_kernel_launches"] == 2
         if expect is not None:
             assert s["detected_grid_w"] == expect, (name, s["detected_grid_w"])
+        # the device's own verdict on "coherent": random rays are sent to the lane kernel
+        assert s["reserved"] == (1 if name.startswith("incoherent") else 0), (name, s["reserved"])
+        parity.assert_exact(c_auto.cast(rays, flags=capi.FLAG_COHERENT), want, name + " (auto: packet or lane launch)")
         host = po.make_host_rays(rays)
         got44 = c.cast(host, flags=capi.FLAG_COHERENT | capi.FLAG_HOST_LAYOUT)
         assert got44.tobytes() == po.unpack_hits(want, host).tobytes()
