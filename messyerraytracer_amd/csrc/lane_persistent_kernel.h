@@ -23,6 +23,8 @@ struct PersistParams {
 };
 
 template <bool ANY_HIT>
+// (69 VGPRs = 7 waves per SIMD; forcing 8 with launch bounds spills and measured the same: the
+// kernel is bound by the divergent 64-byte node fetches, not by occupancy any more)
 __global__ __launch_bounds__(MRT_WG) void trace_lane_persistent_kernel(const TraceParams p, const PersistParams q)
 {
 	extern __shared__ uint32_t lds_stack[];
