@@ -8,8 +8,11 @@ A "step" is one pass of the hot path over one batch: mrt_cast over the 4096x4096
 primary-ray grid (config C3: 1 M-triangle soup, 8-bin SAH BVH2), rays already
 resident in HBM in row-major order, 32-byte hit records written to HBM.  At N > 1
 every rank traces its own full grid (one view per GPU, BVH replicated: weak
-scaling) and the hit records are gathered on rank 0 over RCCL inside the timed
-region, chunked so the copy overlaps the tracing.
+scaling) and the hit records of all views are assembled on rank 0 inside the
+timed region: 4-byte hit tokens travel over RCCL and rank 0 rebuilds the 32-byte
+records (mrt_expand_grid_tokens) on a side stream; frames are pipelined two deep
+(the exchange of frame k runs beside the tracing of frame k+1) and all of them are
+complete when the timed region closes.  --gather records sends the records themselves.
 
 Prints ONE JSON line on rank 0 (contract in the task statement), including
   roofline     algorithmic bytes / measured kernel time vs the 8 TB/s HBM peak
@@ -40,9 +43,15 @@ def parse():
     ap.add_argument("--config", default="C3", help="C2 | C3 (headline) | C5")
     ap.add_argument("--mode", default="cast", choices=["cast", "tiled", "fused"],
                     help="cast: mrt_cast on row-major device rays (headline); tiled: mrt_cast_tiled; fused: mrt_cast_grid")
-    ap.add_argument("--chunks", type=int, default=4, help="row chunks per step at N > 1 (gather/trace overlap)")
+    ap.add_argument("--chunks", type=int, default=1, help="row chunks per step at N > 1 (copy of chunk c beside the tracing of chunk c+1)")
+    ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
+                    help="frames in flight at N > 1: with 2 the exchange of frame k runs beside the tracing of frame k+1 "
+                         "(double-buffered); every frame is complete on rank 0 when the timed region closes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
+    ap.add_argument("--gather", default="tokens", choices=["tokens", "records"],
+                    help="what travels to rank 0 at N > 1: 4-byte hit tokens (the 32-byte records are rebuilt on "
+                         "rank 0, bit-identical) or the 32-byte records themselves")
     ap.add_argument("--grid-tile", type=int, default=0)
     return ap.parse_args()
 
@@ -59,9 +68,12 @@ def cpu_baseline(cfg, verts):
     if po.ref_available():
         rs = po.RefScene(verts)
         rs.cast_rays(rays[: rays.shape[0] // 8], n_threads=cores)
-        t0 = time.perf_counter()
-        rs.cast_rays(rays, n_threads=cores)
-        dt = time.perf_counter() - t0
+        dts = []
+        for _ in range(3):  # median of three passes: ~1 s of wall time, ~16 core-seconds
+            t0 = time.perf_counter()
+            rs.cast_rays(rays, n_threads=cores)
+            dts.append(time.perf_counter() - t0)
+        dt = sorted(dts)[1]
         kind = "reference"
         what = "tinybvh::BVH8_CPU::Intersect (AVX2) under the ThreadPool range split" if po.ref().ref_has_avx2() else \
             "tinybvh::BVH4_CPU::Intersect (SSE) under the ThreadPool range split"
@@ -74,7 +86,7 @@ def cpu_baseline(cfg, verts):
         dt = time.perf_counter() - t0
         kind, what = "port", "oracle/mrt_oracle.c scalar BVH2 walk, OpenMP"
     return dict(value=rays.shape[0] / dt / 1e6, unit="Mrays/s", cores=cores, kind=kind,
-                sample=f"one pass over the full {w}x{h} grid of the same scene ({what}; BVH build excluded)")
+                sample=f"one pass (median of 3 for the reference path) over the full {w}x{h} grid of the same scene ({what}; BVH build excluded)")
 
 
 def main():
@@ -112,23 +124,53 @@ def main():
     rot = np.array([[np.cos(ang), 0, np.sin(ang)], [0, 1, 0], [-np.sin(ang), 0, np.cos(ang)]])
     cam = capi.camera_look(tuple((rot @ o).astype(np.float32)), tuple((rot @ f).astype(np.float32)), w, h, cfg["fov"])
 
+    def view_camera(r):  # the camera of rank r's view (rank 0 rebuilds every view's records from tokens)
+        g = 2.0 * np.pi * r / max(world, 1)
+        m = np.array([[np.cos(g), 0, np.sin(g)], [0, 1, 0], [-np.sin(g), 0, np.cos(g)]])
+        return capi.camera_look(tuple((m @ o).astype(np.float32)), tuple((m @ f).astype(np.float32)), w, h, cfg["fov"])
+    cams = [view_camera(r) for r in range(world)]
+
     n_rays = w * h
     d_rays = torch.empty(n_rays * 32, dtype=torch.uint8, device=device)
     ctx.generate_grid(cam, w, h, 0, h, d_rays)          # untimed: inputs resident in HBM
     trace_ms = []
     dev_flags = capi.FLAG_COHERENT | capi.FLAG_RAYS_ON_DEVICE | capi.FLAG_HITS_ON_DEVICE
 
+    job = None
+    events = []  # pipelined frames: the cast is only queued (MRT_FLAG_ASYNC); timed with events on its stream
+
     def tracer(y0, y1, out):
+        tok = capi.FLAG_TOKEN_OUT if job.token_mode else 0
+        if job.depth > 1:
+            if a.mode == "tiled":
+                raise SystemExit("--mode tiled is blocking: use --depth 1")
+            tok |= capi.FLAG_ASYNC
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(stream)
         if a.mode == "fused":
-            ctx.cast_grid(cam, w, h, y0=y0, y1=y1, hits=out, flags=capi.FLAG_HITS_ON_DEVICE)
+            ctx.cast_grid(cam, w, h, y0=y0, y1=y1, hits=out, flags=capi.FLAG_HITS_ON_DEVICE | tok)
         elif a.mode == "tiled":
+            if tok:
+                raise SystemExit("--mode tiled writes records only: use --gather records")
             ctx.cast_tiled(d_rays.data_ptr() + y0 * w * 32, out, w, y1 - y0)
         else:
-            ctx.cast(d_rays.data_ptr() + y0 * w * 32, out, count=(y1 - y0) * w, flags=dev_flags)
-        trace_ms.append(ctx.stats()["last_trace_ms"])
+            ctx.cast(d_rays.data_ptr() + y0 * w * 32, out, count=(y1 - y0) * w, flags=dev_flags | tok)
+        if job.depth > 1:
+            e1.record(stream)
+            events.append((e0, e1))
+        else:
+            trace_ms.append(ctx.stats()["last_trace_ms"])
+
+    # rehearsal on one GPU only: make rank 0 rebuild its view K times, the load it carries with K ranks
+    rehearse_views = int(os.environ.get("MRT_REHEARSE_VIEWS", "1")) if world == 1 else 1
+
+    def expander(view, y0, y1, tokens, hits, stream):
+        for _ in range(rehearse_views):
+            ctx.expand_grid_tokens(cams[view], w, h, y0, y1, tokens, hits, stream=stream)
 
     chunks = a.chunks if use_dist else 1
-    job = sharded.ShardedViews(w, h, tracer, device, chunks=chunks, gather=not a.no_gather, force_gather=use_dist)
+    job = sharded.ShardedViews(w, h, tracer, device, chunks=chunks, gather=not a.no_gather, force_gather=use_dist,
+                               expander=expander if a.gather == "tokens" else None, depth=a.depth)
 
     def sync():
         if use_dist:
@@ -137,11 +179,14 @@ def main():
 
     for _ in range(a.warmup):
         job.step()
+    job.finish()
     sync()
     trace_ms.clear()
+    events.clear()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         job.step()
+    job.finish()   # every frame's exchange and expansion is queued behind this; sync() waits for them
     sync()
     dt = time.perf_counter() - t0
     if use_dist:
@@ -158,10 +203,15 @@ def main():
             "config": {"workload": f"{a.config}: {verts.shape[0]}-triangle soup (seed {cfg.get('seed')}), 8-bin SAH BVH2, "
                                    f"{w}x{h} primary-ray grid per GPU, closest hit, rays+hits HBM-resident",
                        "entry": {"cast": "mrt_cast(COHERENT)", "tiled": "mrt_cast_tiled", "fused": "mrt_cast_grid"}[a.mode],
-                       "views": world, "gather": "rccl gather to rank 0, %d chunks" % chunks if use_dist and not a.no_gather else "none"},
+                       "views": world, "gather": "none" if not (use_dist and not a.no_gather) else
+                       ("rccl gather of 4-byte hit tokens to rank 0 in %d chunks, 32-byte records rebuilt there" % chunks
+                        if job.token_mode else "rccl gather of 32-byte records to rank 0 in %d chunks" % chunks),
+                       "frames_in_flight": job.depth},
         }
         # roofline of the dominant kernel (trace_lane_kernel): algorithmic bytes / kernel time
         stats_path = os.path.join(ROOT, "tests", "golden", "traversal_stats.json")
+        if events:  # queued casts: detection kernel + trace kernel between the two events
+            trace_ms.extend(e0.elapsed_time(e1) for (e0, e1) in events)
         kernel_ms = float(np.sum(trace_ms)) / a.steps          # per step (all chunks), rank 0
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel": "trace_packet_asm_kernel<false>", "kernel_ms": kernel_ms}

@@ -152,8 +152,19 @@ enum {
 	MRT_FLAG_HOST_LAYOUT    = 1u << 3, /* rays are mrt_host_ray60, hits are mrt_host_hit44 (conversion of
 	                                      gpu_ray_caster.cpp:639-650,442-456 runs on the device)          */
 	MRT_FLAG_BOOL_OUT       = 1u << 4, /* any-hit only: `hits` is uint8_t[count] (cast_rays_any_hit)     */
-	MRT_FLAG_FORCE_SORT     = 1u << 5  /* sort even if count < 256 (tests)                               */
+	MRT_FLAG_FORCE_SORT     = 1u << 5, /* sort even if count < 256 (tests)                               */
+	MRT_FLAG_TOKEN_OUT      = 1u << 6, /* `hits` is uint32_t[count]: per ray a hit token (MRT_TOKEN_MISS, or an
+	                                      opaque name of the winning triangle valid for this scene upload and
+	                                      for identical uploads on other devices).  mrt_expand_tokens rebuilds
+	                                      the full record from (ray, token) bit for bit: the multi-GPU gather
+	                                      moves 4 bytes per ray instead of 32.  Not with BOOL_OUT.            */
+	MRT_FLAG_ASYNC          = 1u << 7  /* mrt_cast / mrt_cast_grid with device-resident rays and hits: queue the
+	                                      work on the context's stream and return without waiting (no timing
+	                                      stats).  Order later work on that stream, or mrt_synchronize().
+	                                      Lets a frame loop keep the device busy while the host queues the
+	                                      exchange of the previous frame (sharded.py).                        */
 };
+#define MRT_TOKEN_MISS 0xFFFFFFFFu
 
 /* kernel variants (options.kernel); 0 picks the default for the batch */
 enum {
@@ -247,6 +258,18 @@ int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t
  * grid_w-wide grid (lets the kernel tile lanes 8x8 instead of 64x1). */
 int mrt_cast_tiled(mrt_ctx *ctx, const mrt_ray32 *d_rays, mrt_hit32 *d_hits,
 		uint32_t grid_w, uint32_t rows, uint32_t query_mask, int mode);
+
+/* ---- hit tokens -> hit records (no reference counterpart: the reference is single-device).
+ * The packed->Intersection readback conversion of gpu_ray_caster.cpp:442-456 applied to
+ * tokens written by a cast with MRT_FLAG_TOKEN_OUT: mrt_hit32 records (mrt_host_hit44 with
+ * MRT_FLAG_HOST_LAYOUT, rays then being mrt_host_ray60), identical to what the cast would
+ * have written without the flag.  Device pointers only.  Asynchronous: enqueued on
+ * `hip_stream` (hipStream_t as void*; 0 = the context's stream) without waiting. */
+int mrt_expand_tokens(mrt_ctx *ctx, const void *d_rays, const uint32_t *d_tokens, void *d_hits,
+		uint64_t count, uint32_t flags, void *hip_stream);
+/* Same for rows [y0,y1) of a camera grid (tokens from mrt_cast_grid, on this or another device). */
+int mrt_expand_grid_tokens(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t grid_h,
+		uint32_t y0, uint32_t y1, const uint32_t *d_tokens, mrt_hit32 *d_hits, void *hip_stream);
 
 /* ---- Morton keys (src/dispatch/ray_sort.h:41-76), exposed for parity tests ---- */
 int mrt_morton_keys(mrt_ctx *ctx, const mrt_ray32 *d_rays, uint64_t count, uint32_t *d_keys);

@@ -17,7 +17,8 @@ LIB_PATH = os.environ.get("MRT_LIB_PATH", os.path.join(HERE, "libmrt_hip.so"))  
 MRT_OK = 0
 ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SCENE, ERR_PENDING, ERR_NOT_PENDING, ERR_OOM, ERR_UNSUPPORTED, ERR_BAD_BVH = range(1, 10)
 MODE_NEAREST, MODE_ANY_HIT = 0, 1
-FLAG_COHERENT, FLAG_RAYS_ON_DEVICE, FLAG_HITS_ON_DEVICE, FLAG_HOST_LAYOUT, FLAG_BOOL_OUT, FLAG_FORCE_SORT = (1 << i for i in range(6))
+FLAG_COHERENT, FLAG_RAYS_ON_DEVICE, FLAG_HITS_ON_DEVICE, FLAG_HOST_LAYOUT, FLAG_BOOL_OUT, FLAG_FORCE_SORT, FLAG_TOKEN_OUT, FLAG_ASYNC = (1 << i for i in range(8))
+TOKEN_MISS = 0xFFFFFFFF
 KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET, KERNEL_PACKET4, KERNEL_PACKET2, KERNEL_PACKET_ASM, KERNEL_LANE_PERSISTENT = range(7)
 
 # every entry point include/mrt_hip.h declares (tests check they are all exported)
@@ -25,7 +26,8 @@ SYMBOLS = [
     "mrt_create", "mrt_destroy", "mrt_last_error", "mrt_status_string", "mrt_version", "mrt_set_stream",
     "mrt_synchronize", "mrt_make_triangles", "mrt_pack_host_triangles", "mrt_bvh2_build", "mrt_upload_scene",
     "mrt_is_available", "mrt_scene_info", "mrt_cast", "mrt_submit", "mrt_collect", "mrt_has_pending",
-    "mrt_camera_look", "mrt_generate_grid", "mrt_cast_grid", "mrt_cast_tiled", "mrt_morton_keys",
+    "mrt_camera_look", "mrt_generate_grid", "mrt_cast_grid", "mrt_cast_tiled", "mrt_expand_tokens",
+    "mrt_expand_grid_tokens", "mrt_morton_keys",
     "mrt_get_stats", "mrt_device_alloc", "mrt_device_free", "mrt_memcpy_h2d", "mrt_memcpy_d2h",
 ]
 
@@ -91,6 +93,9 @@ def load():
     L.mrt_cast_grid.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
     L.mrt_cast_tiled.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.mrt_expand_tokens.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p]
+    L.mrt_expand_grid_tokens.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
+                                         C.c_void_p, C.c_void_p, C.c_void_p]
     L.mrt_morton_keys.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p]
     L.mrt_get_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.mrt_device_alloc.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]
@@ -218,6 +223,8 @@ class Context:
         if hits is None:
             if flags & FLAG_BOOL_OUT:
                 hits = np.zeros(count, dtype=np.uint8)
+            elif flags & FLAG_TOKEN_OUT:
+                hits = np.zeros(count, dtype=np.uint32)
             elif flags & FLAG_HOST_LAYOUT:
                 hits = np.zeros(count, dtype=T.HOST_HIT44)
             else:
@@ -241,6 +248,8 @@ class Context:
         if hits is None:
             if flags & FLAG_BOOL_OUT:
                 hits = np.zeros(count, dtype=np.uint8)
+            elif flags & FLAG_TOKEN_OUT:
+                hits = np.zeros(count, dtype=np.uint32)
             elif flags & FLAG_HOST_LAYOUT:
                 hits = np.zeros(count, dtype=T.HOST_HIT44)
             else:
@@ -258,12 +267,21 @@ class Context:
         y1 = grid_h if y1 is None else y1
         n = grid_w * (y1 - y0)
         if hits is None:
-            hits = np.zeros(n, dtype=np.uint8 if (flags & FLAG_BOOL_OUT) else T.HIT32)
+            hits = np.zeros(n, dtype=np.uint8 if (flags & FLAG_BOOL_OUT) else (np.uint32 if (flags & FLAG_TOKEN_OUT) else T.HIT32))
         self._chk(self.L.mrt_cast_grid(self.h, C.byref(cam), grid_w, grid_h, y0, y1, _ptr(hits), query_mask, mode, flags))
         return hits
 
     def cast_tiled(self, d_rays, d_hits, grid_w, rows, query_mask=0xFFFFFFFF, mode=MODE_NEAREST):
         self._chk(self.L.mrt_cast_tiled(self.h, _ptr(d_rays), _ptr(d_hits), grid_w, rows, query_mask, mode))
+
+    def expand_tokens(self, d_rays, d_tokens, d_hits, count, flags=0, stream=None):
+        """Device pointers; enqueued on `stream` (raw hipStream_t) or the context's stream, not waited for."""
+        self._chk(self.L.mrt_expand_tokens(self.h, _ptr(d_rays), _ptr(d_tokens), _ptr(d_hits), count, flags,
+                                           C.c_void_p(stream) if stream else None))
+
+    def expand_grid_tokens(self, cam, grid_w, grid_h, y0, y1, d_tokens, d_hits, stream=None):
+        self._chk(self.L.mrt_expand_grid_tokens(self.h, C.byref(cam), grid_w, grid_h, y0, y1, _ptr(d_tokens), _ptr(d_hits),
+                                                C.c_void_p(stream) if stream else None))
 
     def morton_keys(self, d_rays, count, d_keys):
         self._chk(self.L.mrt_morton_keys(self.h, _ptr(d_rays), count, _ptr(d_keys)))

@@ -19,6 +19,7 @@
 namespace mrt {
 hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream);
 hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t stream);
+hipError_t launch_expand_tokens(const TraceParams &p, const uint32_t *tokens, hipStream_t stream);
 hipError_t launch_morton_keys(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t *keys, uint32_t *index, hipStream_t stream);
 hipError_t launch_trace_persistent(const TraceParams &p, unsigned long long *next_ray, uint32_t *overflow,
 		uint32_t lds_depth, uint32_t refill, uint32_t blocks, bool any_hit, hipStream_t stream);
@@ -103,14 +104,22 @@ size_t ray_stride(uint32_t flags) { return (flags & MRT_FLAG_HOST_LAYOUT) ? size
 size_t hit_stride(uint32_t flags, int mode)
 {
 	if ((flags & MRT_FLAG_BOOL_OUT) && mode == MRT_MODE_ANY_HIT) return 1;
+	if (flags & MRT_FLAG_TOKEN_OUT) return sizeof(uint32_t);
 	return (flags & MRT_FLAG_HOST_LAYOUT) ? sizeof(mrt_host_hit44) : sizeof(mrt_hit32);
+}
+
+uint32_t out_format(uint32_t flags, int mode)
+{
+	if ((flags & MRT_FLAG_BOOL_OUT) && mode == MRT_MODE_ANY_HIT) return mrt::OUT_BOOL8;
+	if (flags & MRT_FLAG_TOKEN_OUT) return mrt::OUT_TOKEN4;
+	return (flags & MRT_FLAG_HOST_LAYOUT) ? mrt::OUT_HOST44 : mrt::OUT_HIT32;
 }
 
 void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 {
 	std::memset(&p, 0, sizeof(p));
 	p.nodes = ctx->d_nodes; p.nodes4 = ctx->d_nodes4; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold;
-	p.stack_depth = ctx->stack_depth;
+	p.stack_depth = ctx->stack_depth; p.n_tris = ctx->n_tris;
 	if (ctx->opts.stack_override >= ctx->depth && ctx->opts.stack_override <= 64) p.stack_depth = ctx->opts.stack_override;
 	p.counters = ctx->d_counters;
 	p.xcd_swizzle = ctx->opts.xcd_swizzle ? 1 : 0;
@@ -192,6 +201,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded (is_available() == false)");
 	if (mode != MRT_MODE_NEAREST && mode != MRT_MODE_ANY_HIT) return fail(ctx, MRT_ERR_INVALID, "bad mode");
 	if ((flags & MRT_FLAG_BOOL_OUT) && mode != MRT_MODE_ANY_HIT) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT needs any-hit mode");
+	if ((flags & MRT_FLAG_BOOL_OUT) && (flags & MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT and TOKEN_OUT exclude each other");
 	const size_t rs = ray_stride(flags), hs = hit_stride(flags, mode);
 	int rc;
 	const void *d_rays = rays;
@@ -212,7 +222,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	base_params(ctx, p);
 	p.rays = d_rays; p.hits = d_hits; p.count = count; p.query_mask = query_mask;
 	p.in_fmt = (flags & MRT_FLAG_HOST_LAYOUT) ? mrt::IN_HOST60 : mrt::IN_RAY32;
-	p.out_fmt = hs == 1 ? mrt::OUT_BOOL8 : ((flags & MRT_FLAG_HOST_LAYOUT) ? mrt::OUT_HOST44 : mrt::OUT_HIT32);
+	p.out_fmt = out_format(flags, mode);
 	p.lane_map = mrt::MAP_LINEAR;
 	const uint32_t thr = ctx->opts.sort_threshold ? ctx->opts.sort_threshold : 256u; // MIN_BATCH_FOR_SORTING
 	const bool sort = !(flags & MRT_FLAG_COHERENT) && (count >= thr || (flags & MRT_FLAG_FORCE_SORT));
@@ -423,8 +433,11 @@ int mrt_cast(mrt_ctx *ctx, const void *rays, void *hits, uint64_t count, uint32_
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	void *d_hits = nullptr;
 	const bool hits_dev = (flags & MRT_FLAG_HITS_ON_DEVICE) != 0;
+	if ((flags & MRT_FLAG_ASYNC) && !(hits_dev && (flags & MRT_FLAG_RAYS_ON_DEVICE)))
+		return fail(ctx, MRT_ERR_INVALID, "ASYNC needs device-resident rays and hits");
 	int rc = enqueue_cast(ctx, rays, hits_dev ? hits : nullptr, count, query_mask, mode, flags, &d_hits);
 	if (rc) return rc;
+	if (flags & MRT_FLAG_ASYNC) return MRT_OK; // queued on the context's stream; no timing
 	if (!hits_dev) {
 		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, count * hit_stride(flags, mode), hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
@@ -440,7 +453,7 @@ int mrt_submit(mrt_ctx *ctx, const void *rays, uint64_t count, uint32_t query_ma
 	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded");
 	if (count == 0) return MRT_OK;
 	if (!rays) return fail(ctx, MRT_ERR_INVALID, "null rays");
-	if (flags & MRT_FLAG_HITS_ON_DEVICE) return fail(ctx, MRT_ERR_INVALID, "submit keeps results in the context; use mrt_cast for device outputs");
+	if (flags & (MRT_FLAG_HITS_ON_DEVICE | MRT_FLAG_ASYNC)) return fail(ctx, MRT_ERR_INVALID, "submit keeps results in the context; use mrt_cast for device outputs");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	void *d_hits = nullptr;
 	int rc = enqueue_cast(ctx, rays, nullptr, count, query_mask, mode, flags, &d_hits);
@@ -498,6 +511,7 @@ int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t
 	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded");
 	if (ctx->pending) return fail(ctx, MRT_ERR_PENDING, "collect the pending dispatch first");
 	if (flags & MRT_FLAG_HOST_LAYOUT) return fail(ctx, MRT_ERR_UNSUPPORTED, "grid casts write packed hits");
+	if ((flags & MRT_FLAG_BOOL_OUT) && (flags & MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT and TOKEN_OUT exclude each other");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	mrt::TraceParams p;
 	int rc = grid_params(ctx, cam, grid_w, grid_h, y0, y1, p);
@@ -505,16 +519,18 @@ int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t
 	if (p.count == 0) return MRT_OK;
 	const size_t hs = hit_stride(flags, mode);
 	const bool hits_dev = (flags & MRT_FLAG_HITS_ON_DEVICE) != 0;
+	if ((flags & MRT_FLAG_ASYNC) && !hits_dev) return fail(ctx, MRT_ERR_INVALID, "ASYNC needs device-resident hits");
 	void *d_hits = hits;
 	if (!hits_dev) { if ((rc = ensure(ctx, ctx->hits, p.count * hs))) return rc; d_hits = ctx->hits.ptr; }
 	p.hits = d_hits; p.query_mask = query_mask;
-	p.out_fmt = hs == 1 ? mrt::OUT_BOOL8 : mrt::OUT_HIT32;
+	p.out_fmt = out_format(flags, mode);
 	p.lane_map = ctx->opts.grid_tile == 1 ? mrt::MAP_LINEAR : mrt::MAP_TILE8X8;
 	p.kernel = pick_kernel(ctx, true);
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+	if (flags & MRT_FLAG_ASYNC) { ctx->stats.rays_cast += p.count; return MRT_OK; }
 	if (!hits_dev) {
 		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, p.count * hs, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
@@ -549,6 +565,40 @@ int mrt_cast_tiled(mrt_ctx *ctx, const mrt_ray32 *d_rays, mrt_hit32 *d_hits,
 	ctx->stats.last_kernel_launches = 1; ctx->stats.rays_cast += p.count;
 	ctx->stats.last_h2d_ms = ctx->stats.last_sort_ms = ctx->stats.last_d2h_ms = 0.0f;
 	return finish_timing(ctx, false, false, false);
+}
+
+int mrt_expand_tokens(mrt_ctx *ctx, const void *d_rays, const uint32_t *d_tokens, void *d_hits, uint64_t count,
+		uint32_t flags, void *hip_stream)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded");
+	if (count == 0) return MRT_OK;
+	if (!d_rays || !d_tokens || !d_hits) return fail(ctx, MRT_ERR_INVALID, "null rays / tokens / hits");
+	if (flags & (MRT_FLAG_BOOL_OUT | MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_INVALID, "tokens expand to hit records only");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	mrt::TraceParams p;
+	base_params(ctx, p);
+	p.rays = d_rays; p.hits = d_hits; p.count = count;
+	p.in_fmt = (flags & MRT_FLAG_HOST_LAYOUT) ? mrt::IN_HOST60 : mrt::IN_RAY32;
+	p.out_fmt = (flags & MRT_FLAG_HOST_LAYOUT) ? mrt::OUT_HOST44 : mrt::OUT_HIT32;
+	HIP_TRY(ctx, mrt::launch_expand_tokens(p, d_tokens, hip_stream ? (hipStream_t)hip_stream : ctx->stream));
+	return MRT_OK;
+}
+
+int mrt_expand_grid_tokens(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t grid_h,
+		uint32_t y0, uint32_t y1, const uint32_t *d_tokens, mrt_hit32 *d_hits, void *hip_stream)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	mrt::TraceParams p;
+	int rc = grid_params(ctx, cam, grid_w, grid_h, y0, y1, p);
+	if (rc) return rc;
+	if (p.count == 0) return MRT_OK;
+	if (!d_tokens || !d_hits) return fail(ctx, MRT_ERR_INVALID, "null tokens / hits");
+	p.hits = d_hits; p.out_fmt = mrt::OUT_HIT32;
+	HIP_TRY(ctx, mrt::launch_expand_tokens(p, d_tokens, hip_stream ? (hipStream_t)hip_stream : ctx->stream));
+	return MRT_OK;
 }
 
 int mrt_morton_keys(mrt_ctx *ctx, const mrt_ray32 *d_rays, uint64_t count, uint32_t *d_keys)

@@ -128,9 +128,10 @@ __device__ __forceinline__ void load_ray(const TraceParams &p, uint64_t idx, uin
 // Result store: bvh_traverse.comp.glsl:322-327, plus the readback conversion of
 // gpu_ray_caster.cpp:442-456 (OUT_HOST44) / :482-487 (OUT_BOOL8) fused in.
 __device__ __forceinline__ void store_hit(const TraceParams &p, uint64_t idx, const RayRegs &r,
-		float t, int32_t prim, float u, float v, float nx, float ny, float nz, uint32_t layers)
+		float t, int32_t prim, float u, float v, float nx, float ny, float nz, uint32_t layers, uint32_t slot)
 {
 	if (p.out_fmt == OUT_BOOL8) { reinterpret_cast<uint8_t *>(p.hits)[idx] = prim >= 0 ? 1 : 0; return; }
+	if (p.out_fmt == OUT_TOKEN4) { reinterpret_cast<uint32_t *>(p.hits)[idx] = prim >= 0 ? slot : 0xFFFFFFFFu; return; }
 	if (p.out_fmt == OUT_HOST44) {
 		float *h = reinterpret_cast<float *>(p.hits) + idx * 11u;
 		uint32_t *hu = reinterpret_cast<uint32_t *>(h);
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 		const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
 		nx = nn.x; ny = nn.y; nz = nn.z;
 	}
-	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers);
+	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
 
 	if (COUNT) {
 		atomicAdd(&p.counters[0], 1ull);
@@ -295,6 +296,44 @@ __global__ __launch_bounds__(MRT_WG) void grid_rays_kernel(const TraceParams p, 
 	a.x = r.ox; a.y = r.oy; a.z = r.oz; a.w = r.t_max;
 	b.x = r.dx; b.y = r.dy; b.z = r.dz; b.w = r.t_min;
 	q[0] = a; q[1] = b;
+}
+
+// ---- hit tokens -> full hit records (mrt_expand_tokens) -----------------------------------
+// A token names the winning triangle of a ray (leaf-order slot, 0xFFFFFFFF = miss).  Everything
+// else in the record is a function of (ray, triangle): t, u, v come out of one Moller-Trumbore
+// evaluation written exactly as in the traversal kernels, so the rebuilt record is the record
+// the trace would have stored, bit for bit.  This is what lets a multi-GPU gather move 4 bytes
+// per ray over xGMI instead of 32 (sharded.py): the root rebuilds the records from its own copy
+// of the scene and the sender's camera.
+__global__ __launch_bounds__(MRT_WG) void expand_tokens_kernel(const TraceParams p, const uint32_t *tokens)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * MRT_WG + threadIdx.x;
+	if (g >= p.count) return;
+	RayRegs r;
+	uint32_t px = 0, py = 0;
+	if (p.in_fmt == IN_GRID) { px = (uint32_t)(g % p.grid_w); py = (uint32_t)(g / p.grid_w); }
+	load_ray(p, g, px, py, r);
+	const uint32_t slot = tokens[g];
+	if (slot >= p.n_tris) { // miss (0xFFFFFFFF), or a token that is not from this scene: never read out of bounds
+		store_hit(p, g, r, r.t_max, -1, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0u, slot);
+		return;
+	}
+	const float4 *t3 = reinterpret_cast<const float4 *>(p.tri_hot) + (size_t)slot * 3u;
+	const float4 q0 = t3[0], q1 = t3[1], q2 = t3[2];
+	const float pvx = fma_(r.dy, q2.z, -(r.dz * q2.y));
+	const float pvy = fma_(r.dz, q2.x, -(r.dx * q2.z));
+	const float pvz = fma_(r.dx, q2.y, -(r.dy * q2.x));
+	const float det = dot3(q1.x, q1.y, q1.z, pvx, pvy, pvz);
+	const float inv_det = 1.0f / det;
+	const float tvx = r.ox - q0.x, tvy = r.oy - q0.y, tvz = r.oz - q0.z;
+	const float u = dot3(tvx, tvy, tvz, pvx, pvy, pvz) * inv_det;
+	const float qvx = fma_(tvy, q1.z, -(tvz * q1.y));
+	const float qvy = fma_(tvz, q1.x, -(tvx * q1.z));
+	const float qvz = fma_(tvx, q1.y, -(tvy * q1.x));
+	const float v = dot3(r.dx, r.dy, r.dz, qvx, qvy, qvz) * inv_det;
+	const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
+	const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[slot];
+	store_hit(p, g, r, t, (int32_t)__float_as_uint(q0.w), u, v, nn.x, nn.y, nn.z, __float_as_uint(q1.w), slot);
 }
 
 // ---- row-width detection for coherent batches ------------------------------------------
@@ -552,6 +591,14 @@ hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t st
 	if (p.count == 0) return hipSuccess;
 	const uint64_t blocks = (p.count + MRT_WG - 1) / MRT_WG;
 	hipLaunchKernelGGL(grid_rays_kernel, dim3((uint32_t)blocks), dim3(MRT_WG), 0, stream, p, out);
+	return hipGetLastError();
+}
+
+hipError_t launch_expand_tokens(const TraceParams &p, const uint32_t *tokens, hipStream_t stream)
+{
+	if (p.count == 0) return hipSuccess;
+	const uint64_t blocks = (p.count + MRT_WG - 1) / MRT_WG;
+	hipLaunchKernelGGL(expand_tokens_kernel, dim3((uint32_t)blocks), dim3(MRT_WG), 0, stream, p, tokens);
 	return hipGetLastError();
 }
 

@@ -69,7 +69,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_persistent_kernel(const Tra
 				const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
 				nx = nn.x; ny = nn.y; nz = nn.z;
 			}
-			store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers);
+			store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
 			has_ray = false;
 		}
 		const unsigned long long idle_mask = __ballot(idle);

@@ -58,7 +58,9 @@ constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kLastInLeaf = 1u;
 
 enum InFmt : uint32_t { IN_RAY32 = 0, IN_HOST60 = 1, IN_GRID = 2 };
-enum OutFmt : uint32_t { OUT_HIT32 = 0, OUT_HOST44 = 1, OUT_BOOL8 = 2 };
+// OUT_TOKEN4: one u32 per ray = leaf-order slot of the winning triangle (0xFFFFFFFF = miss); the
+// full record is rebuilt from (ray, slot) by expand_tokens_kernel, bit for bit
+enum OutFmt : uint32_t { OUT_HIT32 = 0, OUT_HOST44 = 1, OUT_BOOL8 = 2, OUT_TOKEN4 = 3 };
 enum LaneMap : uint32_t { MAP_LINEAR = 0, MAP_TILE8X8 = 1, MAP_AUTO = 2 };
 
 struct TraceParams {
@@ -83,6 +85,7 @@ struct TraceParams {
 	uint32_t kernel;           // MRT_KERNEL_LANE / MRT_KERNEL_PACKET
 	uint32_t stack_depth;      // LDS stack entries per lane
 	uint32_t xcd_swizzle;      // 1: remap blockIdx so each XCD owns a contiguous band
+	uint32_t n_tris;           // rows in tri_hot / tri_cold (token validation)
 	mrt_camera cam;
 };
 

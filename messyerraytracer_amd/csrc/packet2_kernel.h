@@ -166,7 +166,7 @@ __device__ __forceinline__ void pkt2_finish(const TraceParams &p, const Pkt2 &k,
 		nx = nn.x; ny = nn.y; nz = nn.z;
 	}
 	RayRegs r = k.r;
-	store_hit(p, ray_idx, r, k.best_t, prim, k.best_u, k.best_v, nx, ny, nz, layers);
+	store_hit(p, ray_idx, r, k.best_t, prim, k.best_u, k.best_v, nx, ny, nz, layers, k.best_slot);
 	if (count) {
 		atomicAdd(&p.counters[0], 1ull);
 		atomicAdd(&p.counters[1], (unsigned long long)n_tris);

@@ -182,7 +182,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_packet4_kernel(const TraceParams
 		nx = nn.x; ny = nn.y; nz = nn.z;
 	}
 	if (!valid) return;
-	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers);
+	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
 
 	if (COUNT) {
 		atomicAdd(&p.counters[0], 1ull);

@@ -168,7 +168,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_packet_kernel(const TraceParams 
 		const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
 		nx = nn.x; ny = nn.y; nz = nn.z;
 	}
-	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers);
+	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
 
 	if (COUNT) { // wave-level counts: each wave-step is charged to every live lane
 		atomicAdd(&p.counters[0], 1ull);

@@ -387,6 +387,123 @@ def test_both_kernels_on_every_kind_of_batch(built, kernel):
     c.close()
 
 
+def test_async_flag_queues_casts_back_to_back(ctx, soup1k):
+    """MRT_FLAG_ASYNC: casts only queue work on the context's stream; a frame loop issues several
+    (coherent, sorted, grid; records and tokens) and waits once.  They share the context's scratch
+    buffers, so stream order alone must keep them apart."""
+    v, scene, osc = soup1k
+    scene.upload(ctx)
+    w, h = 96, 80
+    cam = capi.camera_look((0, 0, -12), (0, 0, 1), w, h, 50.0)
+    grid = po.grid_rays((0, 0, -12), (0, 0, 1), w, h, 50.0)
+    inc = synth.incoherent_rays(70000, 5)      # large enough for the persistent lane kernel
+    want_g, want_i = osc.trace(grid), osc.trace(inc)
+    dev = capi.FLAG_RAYS_ON_DEVICE | capi.FLAG_HITS_ON_DEVICE | capi.FLAG_ASYNC
+    dg, di = DeviceArray(ctx, grid.nbytes).upload(grid), DeviceArray(ctx, inc.nbytes).upload(inc)
+    outs = [DeviceArray(ctx, max(grid.shape[0], inc.shape[0]) * 32) for _ in range(5)]
+    ctx.cast(dg.ptr, outs[0].ptr, count=grid.shape[0], flags=dev | capi.FLAG_COHERENT)
+    ctx.cast(di.ptr, outs[1].ptr, count=inc.shape[0], flags=dev)                       # Morton sort + lane kernel
+    ctx.cast(di.ptr, outs[2].ptr, count=inc.shape[0], flags=dev | capi.FLAG_COHERENT)  # judged incoherent on the device
+    ctx.cast_grid(cam, w, h, hits=outs[3].ptr, flags=capi.FLAG_HITS_ON_DEVICE | capi.FLAG_ASYNC)
+    ctx.cast(dg.ptr, outs[4].ptr, count=grid.shape[0], flags=dev | capi.FLAG_COHERENT | capi.FLAG_TOKEN_OUT)
+    ctx.synchronize()
+    parity.assert_exact(outs[0].download(T.HIT32, grid.shape[0]), want_g, "async coherent")
+    parity.assert_exact(outs[1].download(T.HIT32, inc.shape[0]), want_i, "async sorted")
+    parity.assert_exact(outs[2].download(T.HIT32, inc.shape[0]), want_i, "async mislabelled coherent")
+    parity.assert_exact(outs[3].download(T.HIT32, grid.shape[0]), want_g, "async cast_grid")
+    tok = outs[4].download(np.uint32, grid.shape[0])
+    assert np.array_equal(tok != capi.TOKEN_MISS, want_g["prim_id"] >= 0)
+    with pytest.raises(capi.MrtError):   # host arrays cannot be left in flight
+        ctx.cast(grid, flags=capi.FLAG_ASYNC)
+    for d in [dg, di] + outs:
+        d.free()
+
+
+@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET4,
+                                    capi.KERNEL_PACKET2, capi.KERNEL_PACKET_ASM, capi.KERNEL_LANE_PERSISTENT])
+def test_hit_tokens_expand_to_identical_records(built, kernel):
+    """MRT_FLAG_TOKEN_OUT + mrt_expand_tokens == the records of a plain cast, byte for byte
+    (what lets the multi-GPU gather move 4 bytes per ray instead of 32)."""
+    c = capi.Context(0, kernel=kernel)
+    other = capi.Context(0)          # stands for another rank: same scene uploaded independently
+    n_tris = 3000
+    v = synth.soup(n_tris, 0.35, 17)
+    layers = (1 << (np.arange(n_tris) % 3)).astype(np.uint32)
+    scene, osc = capi.Scene(v, None, layers), po.OracleScene(v, None, layers)
+    scene.upload(c)
+    capi.Scene(v, None, layers).upload(other)
+    grid = po.grid_rays((0, 0, -12), (0, 0, 1), 100, 70, 50.0)
+    inc = synth.incoherent_rays(5000, 23)
+    inc["t_min"][:300] = 3.0
+    inc["t_max"][:300] = 3.0                                             # degenerate: misses with t = t_max
+    inc["t_max"][600:900] = 1.5
+    for rays, name in ((grid, "grid"), (inc, "incoherent")):
+        n = rays.shape[0]
+        d_rays = DeviceArray(c, rays.nbytes).upload(rays)
+        d_tok, d_hits = DeviceArray(c, n * 4), DeviceArray(c, n * 32)
+        o_rays = DeviceArray(other, rays.nbytes).upload(rays)
+        o_tok, o_hits = DeviceArray(other, n * 4), DeviceArray(other, n * 32)
+        for mask in (0xFFFFFFFF, 0x5):
+            want = osc.trace(rays, query_mask=mask)
+            for flags in (capi.FLAG_COHERENT, 0):
+                tok = c.cast(rays, query_mask=mask, flags=flags | capi.FLAG_TOKEN_OUT)
+                assert tok.dtype == np.uint32 and np.array_equal(tok != capi.TOKEN_MISS, want["prim_id"] >= 0)
+                assert (tok[tok != capi.TOKEN_MISS] < n_tris).all()
+                d_tok.upload(tok)
+                c.expand_tokens(d_rays.ptr, d_tok.ptr, d_hits.ptr, n)
+                c.synchronize()
+                parity.assert_exact(d_hits.download(T.HIT32, n), want, f"{name} tokens mask={mask:#x} flags={flags}")
+                # the tokens mean the same on a device that uploaded the same scene by itself
+                o_tok.upload(tok)
+                other.expand_tokens(o_rays.ptr, o_tok.ptr, o_hits.ptr, n)
+                other.synchronize()
+                assert o_hits.download(T.HIT32, n).tobytes() == want.tobytes()
+            # any-hit tokens name SOME intersected triangle: the rebuilt record is a real hit of that triangle
+            tok = c.cast(rays, query_mask=mask, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_COHERENT | capi.FLAG_TOKEN_OUT)
+            assert np.array_equal(tok != capi.TOKEN_MISS, want["prim_id"] >= 0)
+            d_tok.upload(tok)
+            c.expand_tokens(d_rays.ptr, d_tok.ptr, d_hits.ptr, n)
+            c.synchronize()
+            rec = d_hits.download(T.HIT32, n)
+            hit = want["prim_id"] >= 0
+            assert (rec["t"][hit] >= want["t"][hit]).all() and (rec["prim_id"][~hit] == -1).all()
+            same = hit & (rec["prim_id"] == want["prim_id"])
+            assert rec[same].tobytes() == want[same].tobytes()
+        # tokens that are not from this scene never make the kernel read out of bounds: they read as misses
+        bad = np.full(n, n_tris + 12345, dtype=np.uint32)
+        d_tok.upload(bad)
+        c.expand_tokens(d_rays.ptr, d_tok.ptr, d_hits.ptr, n)
+        c.synchronize()
+        assert (d_hits.download(T.HIT32, n)["prim_id"] == -1).all()
+        # 60-byte rays / 44-byte records
+        host = po.make_host_rays(rays)
+        want44 = c.cast(host, flags=capi.FLAG_HOST_LAYOUT)
+        tok = c.cast(host, flags=capi.FLAG_HOST_LAYOUT | capi.FLAG_TOKEN_OUT)
+        h_rays = DeviceArray(c, host.nbytes).upload(host)
+        h_hits = DeviceArray(c, n * 44)
+        d_tok.upload(tok)
+        c.expand_tokens(h_rays.ptr, d_tok.ptr, h_hits.ptr, n, flags=capi.FLAG_HOST_LAYOUT)
+        c.synchronize()
+        assert h_hits.download(T.HOST_HIT44, n).tobytes() == want44.tobytes()
+        for d in (d_rays, d_tok, d_hits, o_rays, o_tok, o_hits, h_rays, h_hits):
+            d.free()
+    # camera grids: the expanding side regenerates the rays from the camera (rows of a larger grid too)
+    cam = capi.camera_look((0, 0, -12), (0, 0, 1), 100, 70, 50.0)
+    want = c.cast_grid(cam, 100, 70)
+    parity.assert_exact(want, osc.trace(grid), "cast_grid")
+    for (y0, y1) in ((0, 70), (13, 41)):
+        m = 100 * (y1 - y0)
+        tok = c.cast_grid(cam, 100, 70, y0=y0, y1=y1, flags=capi.FLAG_TOKEN_OUT)
+        o_tok, o_hits = DeviceArray(other, m * 4).upload(tok), DeviceArray(other, m * 32)
+        other.expand_grid_tokens(cam, 100, 70, y0, y1, o_tok.ptr, o_hits.ptr)
+        other.synchronize()
+        assert o_hits.download(T.HIT32, m).tobytes() == want[y0 * 100:y1 * 100].tobytes()
+        o_tok.free(); o_hits.free()
+    with pytest.raises(capi.MrtError):
+        c.cast(grid, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT | capi.FLAG_TOKEN_OUT)
+    c.close(); other.close()
+
+
 # ---------------------------------------------------------------------------
 # BASELINE.json configs at full size
 # ---------------------------------------------------------------------------
@@ -421,6 +538,13 @@ def _full_grid_case(ctx, name, oracle_rows):
     assert d_hits.download(T.HIT32, w * h).tobytes() == got.tobytes(), "linear vs tiled lane mapping"
     ctx.cast_tiled(d_rays.ptr, d_hits.ptr, w, h)
     assert d_hits.download(T.HIT32, w * h).tobytes() == got.tobytes(), "cast_tiled vs cast_grid"
+    # 4-byte hit tokens + expansion == the records (the multi-GPU exchange format)
+    d_tok = DeviceArray(ctx, w * h * 4)
+    ctx.cast(d_rays.ptr, d_tok.ptr, count=w * h, flags=capi.FLAG_COHERENT | capi.FLAG_RAYS_ON_DEVICE | capi.FLAG_HITS_ON_DEVICE | capi.FLAG_TOKEN_OUT)
+    ctx.expand_grid_tokens(cam, w, h, 0, h, d_tok.ptr, d_hits.ptr)
+    ctx.synchronize()
+    assert d_hits.download(T.HIT32, w * h).tobytes() == got.tobytes(), "tokens + expansion vs records"
+    d_tok.free()
     d_rays.free(); d_hits.free()
     shards = [ctx.cast_grid(cam, w, h, y0=r * h // 4, y1=(r + 1) * h // 4) for r in range(4)]
     assert np.concatenate(shards).tobytes() == got.tobytes(), "row-sharded result differs"

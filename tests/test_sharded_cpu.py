@@ -22,14 +22,14 @@ def _free_port():
     return p
 
 
-def _pattern(y0, y1, width, view=0):
-    """32 bytes per ray that encode (view, y, x)."""
+def _pattern(y0, y1, width, view=0, salt=0):
+    """32 bytes per ray that encode (view, y, x); `salt` tells frames apart."""
     ys = np.arange(y0, y1, dtype=np.uint32)[:, None]
     xs = np.arange(width, dtype=np.uint32)[None, :]
     rec = np.zeros((y1 - y0, width, 8), dtype=np.uint32)
     rec[..., 0] = ys
     rec[..., 1] = xs
-    rec[..., 2] = ys * 65599 + xs * 31 + view
+    rec[..., 2] = ys * 65599 + xs * 31 + view + salt
     rec[..., 7] = view
     return rec
 
@@ -40,30 +40,48 @@ def _worker(rank, world, port, width, rows, chunks, kind, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     dev = torch.device("cpu")
     calls = []
+    opts = kind.split("-")
+    kind = opts[0]
+    tokens = "tokens" in opts  # 4 bytes per ray travel, rank 0 rebuilds the 32-byte records
+    depth = 2 if "pipe" in opts else 1  # frames pipelined: the exchange of frame k beside the tracing of frame k+1
+    frame = [0]
 
     def tracer(y0, y1, out):
         calls.append((y0, y1))
-        out.copy_(torch.from_numpy(_pattern(y0, y1, width, rank if kind == "views" else 0).view(np.uint8).reshape(-1)))
+        rec = _pattern(y0, y1, width, rank if kind == "views" else 0, 1000 * frame[0])
+        src = np.ascontiguousarray(rec[..., 2]) if tokens else rec  # the token is word 2 of the record
+        out.copy_(torch.from_numpy(src.view(np.uint8).reshape(-1)))
+
+    def rebuild(view, y0, y1, tok, hits, stream):
+        assert stream is None  # no side stream on the CPU
+        rec = _pattern(y0, y1, width, view)  # salt unknown here: word 2 is overwritten with what arrived
+        rec[..., 2] = tok.numpy().view(np.uint32).reshape(y1 - y0, width)  # what travelled, not what we expect
+        hits.copy_(torch.from_numpy(rec.view(np.uint8).reshape(-1)))
 
     if kind == "grid":
-        job = sharded.ShardedGrid(width, rows, tracer, dev, chunks=chunks)
+        job = sharded.ShardedGrid(width, rows, tracer, dev, chunks=chunks,
+                                  expander=(lambda y0, y1, t, h, s: rebuild(0, y0, y1, t, h, s)) if tokens else None)
         want_rows = sharded.row_block(rank, world, rows)
     else:
-        job = sharded.ShardedViews(width, rows, tracer, dev, chunks=chunks)
+        job = sharded.ShardedViews(width, rows, tracer, dev, chunks=chunks, expander=rebuild if tokens else None, depth=depth)
         want_rows = (0, rows)
-    for _ in range(2):  # two steps: buffers are reused
+    assert job.token_mode == tokens
+    for k in range(3):  # three steps: buffers (two sets of them when pipelined) are reused
         calls.clear()
+        frame[0] = k
         img = job.step()
+    if depth > 1:
+        job.finish()
     ok = calls[0][0] == want_rows[0] and calls[-1][1] == want_rows[1] and \
         all(calls[i][1] == calls[i + 1][0] for i in range(len(calls) - 1))
     if rank == 0:
         got = img.numpy()
         if kind == "grid":
-            want = _pattern(0, rows, width).view(np.uint8).reshape(-1)
+            want = _pattern(0, rows, width, 0, 2000).view(np.uint8).reshape(-1)
             ok = ok and np.array_equal(got, want)
         else:
             for r in range(world):
-                ok = ok and np.array_equal(got[r], _pattern(0, rows, width, r).view(np.uint8).reshape(-1))
+                ok = ok and np.array_equal(got[r], _pattern(0, rows, width, r, 2000).view(np.uint8).reshape(-1))
     else:
         ok = ok and img is None
     q.put((rank, bool(ok)))
@@ -72,7 +90,11 @@ def _worker(rank, world, port, width, rows, chunks, kind, q):
 
 
 @pytest.mark.parametrize("kind,width,rows,chunks", [("grid", 64, 48, 4), ("grid", 33, 37, 3), ("grid", 16, 2, 8),
-                                                    ("views", 32, 24, 4), ("views", 8, 5, 2)])
+                                                    ("views", 32, 24, 4), ("views", 8, 5, 2),
+                                                    ("grid-tokens", 64, 48, 4), ("grid-tokens", 33, 37, 3),
+                                                    ("views-tokens", 32, 24, 4), ("views-tokens", 8, 5, 2),
+                                                    ("views-pipe", 32, 24, 1), ("views-tokens-pipe", 32, 24, 1),
+                                                    ("views-tokens-pipe", 8, 5, 2)])
 def test_world_size_2_gather(kind, width, rows, chunks):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
