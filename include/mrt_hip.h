@@ -174,8 +174,10 @@ enum {
 	MRT_KERNEL_PACKET4 = 3, /* packet walk over the 4-wide collapse of the same BVH2 (128-B fetches) */
 	MRT_KERNEL_PACKET2 = 4, /* two packets per wave advanced in lockstep (two fetch chains in flight)  */
 	MRT_KERNEL_PACKET_ASM = 5, /* packet walk with the hand-written gfx950 node loop (default for coherent batches) */
-	MRT_KERNEL_LANE_PERSISTENT = 6 /* lane kernel with resident waves pulling rays from a counter (default for
-	                                  large incoherent batches), short LDS stack + HBM spill               */
+	MRT_KERNEL_LANE_PERSISTENT = 6, /* lane kernel with resident waves pulling rays from a counter, short LDS
+	                                  stack + HBM spill, node / leaf phases                                */
+	MRT_KERNEL_LANE4_PERSISTENT = 7 /* the same over the 4-wide collapse of the BVH, one 128-byte line per step
+	                                  (default for large incoherent batches)                               */
 };
 
 typedef struct mrt_options {
@@ -193,7 +195,9 @@ typedef struct mrt_options {
 	uint32_t sort_key;        /* 0: origin cell + direction Morton key (default), 1: the reference's
 	                             direction-only key (ray_sort.h:64-76); the order never changes results */
 	uint32_t refill;          /* persistent lane kernel: refill a wave when this many lanes are idle (default 16) */
-	uint32_t reserved[5];
+	uint32_t leaf_wait;       /* persistent lane kernel: leave the node phase when this many lanes stand at a
+	                             leaf (default 16; 64 = classic while-while)                           */
+	uint32_t reserved[4];
 } mrt_options;
 
 typedef struct mrt_ctx mrt_ctx;

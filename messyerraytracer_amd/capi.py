@@ -19,7 +19,8 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SCENE, ERR_PENDING, ERR_NOT_PENDING,
 MODE_NEAREST, MODE_ANY_HIT = 0, 1
 FLAG_COHERENT, FLAG_RAYS_ON_DEVICE, FLAG_HITS_ON_DEVICE, FLAG_HOST_LAYOUT, FLAG_BOOL_OUT, FLAG_FORCE_SORT, FLAG_TOKEN_OUT, FLAG_ASYNC = (1 << i for i in range(8))
 TOKEN_MISS = 0xFFFFFFFF
-KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET, KERNEL_PACKET4, KERNEL_PACKET2, KERNEL_PACKET_ASM, KERNEL_LANE_PERSISTENT = range(7)
+KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET, KERNEL_PACKET4, KERNEL_PACKET2, KERNEL_PACKET_ASM, KERNEL_LANE_PERSISTENT, \
+    KERNEL_LANE4_PERSISTENT = range(8)
 
 # every entry point include/mrt_hip.h declares (tests check they are all exported)
 SYMBOLS = [
@@ -42,7 +43,8 @@ class Options(C.Structure):
     _fields_ = [("struct_size", C.c_uint32), ("kernel", C.c_uint32), ("count_visits", C.c_uint32),
                 ("sort_threshold", C.c_uint32), ("grid_tile", C.c_uint32), ("tile_w_log2", C.c_uint32),
                 ("xcd_swizzle", C.c_uint32), ("stack_override", C.c_uint32), ("tile_order", C.c_uint32),
-                ("sort_key", C.c_uint32), ("refill", C.c_uint32), ("reserved", C.c_uint32 * 5)]
+                ("sort_key", C.c_uint32), ("refill", C.c_uint32), ("leaf_wait", C.c_uint32),
+                ("reserved", C.c_uint32 * 4)]
 
 
 class Camera(C.Structure):
@@ -161,7 +163,8 @@ class Context:
 
     def __init__(self, device: int = 0, kernel: int = KERNEL_AUTO, count_visits: bool = False,
                  sort_threshold: int = 0, grid_tile: int = 0, tile_w_log2: int = 0, xcd_swizzle: int = 0,
-                 stack_override: int = 0, tile_order: int = 0, sort_key: int = 0, refill: int = 0):
+                 stack_override: int = 0, tile_order: int = 0, sort_key: int = 0, refill: int = 0,
+                 leaf_wait: int = 0):
         self.L = load()
         opts = Options()
         opts.struct_size = C.sizeof(Options)
@@ -175,6 +178,7 @@ class Context:
         opts.tile_order = tile_order
         opts.sort_key = sort_key
         opts.refill = refill
+        opts.leaf_wait = leaf_wait
         self.h = C.c_void_p()
         rc = self.L.mrt_create(device, C.byref(opts), C.byref(self.h))
         if rc:

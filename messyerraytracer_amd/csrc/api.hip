@@ -22,7 +22,7 @@ hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t st
 hipError_t launch_expand_tokens(const TraceParams &p, const uint32_t *tokens, hipStream_t stream);
 hipError_t launch_morton_keys(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t *keys, uint32_t *index, hipStream_t stream);
 hipError_t launch_trace_persistent(const TraceParams &p, unsigned long long *next_ray, uint32_t *overflow,
-		uint32_t lds_depth, uint32_t refill, uint32_t blocks, bool any_hit, hipStream_t stream);
+		uint32_t lds_depth, uint32_t refill, uint32_t leaf_wait, uint32_t blocks, bool any_hit, hipStream_t stream);
 hipError_t launch_origin_dir_keys(const void *rays, uint32_t in_fmt, uint64_t count, const float lo[3], const float hi[3],
 		uint32_t *keys, uint32_t *index, hipStream_t stream);
 hipError_t launch_detect_grid(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t tile_w_log2,
@@ -45,7 +45,7 @@ struct mrt_ctx {
 	mrt::DevNode *d_nodes = nullptr; mrt::TriHot *d_hot = nullptr; mrt::TriCold *d_cold = nullptr;
 	mrt::Dev4Node *d_nodes4 = nullptr; uint32_t n_nodes4 = 0;
 	float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
-	uint32_t n_nodes = 0, n_tris = 0, depth = 0, stack_depth = 0;
+	uint32_t n_nodes = 0, n_tris = 0, depth = 0, stack_depth = 0, stack4 = 0;
 	bool scene = false;
 	// per-dispatch buffers (grow only, x1.5: gpu_ray_caster.cpp:776-817)
 	DevBuf rays, hits, keys_in, keys_out, idx_in, idx_out, sort_tmp, overflow;
@@ -132,7 +132,7 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 // primary-ray grids), one lane per ray for everything else (sorted / incoherent batches).
 uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent)
 {
-	if (ctx->opts.kernel >= MRT_KERNEL_LANE && ctx->opts.kernel <= MRT_KERNEL_LANE_PERSISTENT) return ctx->opts.kernel;
+	if (ctx->opts.kernel >= MRT_KERNEL_LANE && ctx->opts.kernel <= MRT_KERNEL_LANE4_PERSISTENT) return ctx->opts.kernel;
 	// (PACKET4 halves the fetch chain but measured 7 % slower at C3: the walk is bound by
 	// instruction issue, and ordering four children costs more scalar work than it saves)
 	// PACKET_ASM: same walk with the hand-written node loop (the compiler's loop is scalar-ALU bound)
@@ -171,6 +171,11 @@ int device_sort(mrt_ctx *ctx, const void *d_rays, uint32_t in_fmt, uint64_t coun
 int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit, bool persistent)
 {
 	int rc;
+	// the 4-wide walk (default for large incoherent batches: 7.8 ms against 11.0 ms at C4) exists in
+	// persistent form only
+	const bool wide4 = ctx->d_nodes4 != nullptr && (ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
+			(ctx->opts.kernel == MRT_KERNEL_AUTO && persistent));
+	if (wide4 && !ctx->opts.count_visits) persistent = true;
 	if (!persistent || ctx->opts.count_visits) {
 		p.kernel = MRT_KERNEL_LANE;
 		HIP_TRY(ctx, mrt::launch_trace(p, any_hit, ctx->opts.count_visits != 0, ctx->stream));
@@ -183,14 +188,16 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 	const uint64_t needed = (count + 255u) / 256u;
 	if (blocks > needed) blocks = needed;
 	uint32_t *ovf = nullptr;
-	if (ctx->depth > lds_depth) { // deeper entries spill to [depth - lds_depth][thread] in HBM
-		if ((rc = ensure(ctx, ctx->overflow, (size_t)(ctx->depth - lds_depth) * blocks * 256u * 4u))) return rc;
+	const uint32_t need = wide4 ? ctx->stack4 : ctx->depth; // entries one ray can have pending
+	if (need > lds_depth) { // deeper entries spill to [depth - lds_depth][thread] in HBM
+		if ((rc = ensure(ctx, ctx->overflow, (size_t)(need - lds_depth) * blocks * 256u * 4u))) return rc;
 		ovf = (uint32_t *)ctx->overflow.ptr;
 	}
+	p.kernel = wide4 ? MRT_KERNEL_LANE4_PERSISTENT : MRT_KERNEL_LANE_PERSISTENT;
 	unsigned long long *next_ray = ctx->d_counters + 12;
 	HIP_TRY(ctx, hipMemsetAsync(next_ray, 0, sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace_persistent(p, next_ray, ovf, lds_depth, ctx->opts.refill ? ctx->opts.refill : 16u,
-			(uint32_t)blocks, any_hit, ctx->stream));
+			ctx->opts.leaf_wait ? ctx->opts.leaf_wait : 16u, (uint32_t)blocks, any_hit, ctx->stream));
 	return MRT_OK;
 }
 
@@ -237,7 +244,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	// trace kernel tile its lanes (no host round trip: the kernel reads the answer from HBM).
 	// Timed with the sort as pre-processing (last_sort_ms); last_trace_ms is the trace kernel alone.
 	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 4096 && ctx->opts.grid_tile != 1 &&
-			p.kernel != MRT_KERNEL_LANE_PERSISTENT;
+			p.kernel != MRT_KERNEL_LANE_PERSISTENT && p.kernel != MRT_KERNEL_LANE4_PERSISTENT;
 	if (detect) {
 		uint32_t *d_auto = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);
 		HIP_TRY(ctx, mrt::launch_detect_grid(d_rays, p.in_fmt, count, p.tile_w_log2, ctx->d_counters + 16, d_auto, ctx->stream));
@@ -257,8 +264,9 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	} else {
 		// large incoherent batches: resident waves that pull rays from a counter (no counting variant)
 		const bool persistent = !ctx->opts.count_visits && p.lane_map == mrt::MAP_LINEAR &&
-				(p.kernel == MRT_KERNEL_LANE_PERSISTENT || (ctx->opts.kernel == MRT_KERNEL_AUTO && p.kernel == MRT_KERNEL_LANE && count >= 65536));
-		if (p.kernel == MRT_KERNEL_LANE_PERSISTENT || p.kernel == MRT_KERNEL_LANE) {
+				(p.kernel == MRT_KERNEL_LANE_PERSISTENT || p.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
+				 (ctx->opts.kernel == MRT_KERNEL_AUTO && p.kernel == MRT_KERNEL_LANE && count >= 65536));
+		if (p.kernel == MRT_KERNEL_LANE_PERSISTENT || p.kernel == MRT_KERNEL_LANE4_PERSISTENT || p.kernel == MRT_KERNEL_LANE) {
 			if ((rc = launch_lane(ctx, p, count, any, persistent))) return rc;
 		} else HIP_TRY(ctx, mrt::launch_trace(p, any, ctx->opts.count_visits != 0, ctx->stream));
 	}
@@ -388,7 +396,9 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	free_scene(ctx);
 	hipError_t e;
-	const bool want4 = ctx->opts.kernel == MRT_KERNEL_PACKET4; // the 4-wide layout is resident only when asked for
+	// the 4-wide layout is resident only when a kernel that walks it is asked for
+	const bool want4 = ctx->opts.kernel == MRT_KERNEL_PACKET4 || ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
+			ctx->opts.kernel == MRT_KERNEL_AUTO;
 	if ((e = hipMalloc(&ctx->d_nodes, (size_t)h.n_nodes * sizeof(mrt::DevNode))) != hipSuccess ||
 			// +16 B: the dual-packet kernel fetches 64 B at a 48-B triangle (the tail is never used)
 			(e = hipMalloc(&ctx->d_hot, (size_t)h.n_tris * sizeof(mrt::TriHot) + 16)) != hipSuccess ||
@@ -405,7 +415,7 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	for (int c = 0; c < 3; c++) { ctx->bounds_lo[c] = h.bounds_lo[c]; ctx->bounds_hi[c] = h.bounds_hi[c]; }
 	cleanup();
 	if (e != hipSuccess) { free_scene(ctx); std::snprintf(ctx->err, sizeof(ctx->err), "scene upload failed: %s", hipGetErrorString(e)); return MRT_ERR_HIP; }
-	ctx->n_nodes = h.n_nodes; ctx->n_tris = h.n_tris; ctx->depth = h.depth;
+	ctx->n_nodes = h.n_nodes; ctx->n_tris = h.n_tris; ctx->depth = h.depth; ctx->stack4 = h.stack4;
 	// LDS stack entries per lane: what this BVH can need, rounded up to 8, at most 64.
 	ctx->stack_depth = ((h.depth + 7u) / 8u) * 8u;
 	if (ctx->stack_depth < 8) ctx->stack_depth = 8;

@@ -574,15 +574,21 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 
 // Persistent lane kernel: `blocks` workgroups stay resident and pull rays from *next_ray.
 hipError_t launch_trace_persistent(const TraceParams &p, unsigned long long *next_ray, uint32_t *overflow,
-		uint32_t lds_depth, uint32_t refill, uint32_t blocks, bool any_hit, hipStream_t stream)
+		uint32_t lds_depth, uint32_t refill, uint32_t leaf_wait, uint32_t blocks, bool any_hit, hipStream_t stream)
 {
 	if (p.count == 0 || blocks == 0) return hipSuccess;
 	PersistParams q;
 	q.next_ray = next_ray; q.overflow = overflow; q.overflow_stride = blocks * MRT_WG;
-	q.lds_depth = lds_depth; q.refill = refill;
+	q.lds_depth = lds_depth; q.refill = refill; q.leaf_wait = leaf_wait ? leaf_wait : 1u;
 	const size_t lds = (size_t)(MRT_WG / MRT_WAVE) * lds_depth * MRT_WAVE * sizeof(uint32_t);
-	if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
-	else hipLaunchKernelGGL((trace_lane_persistent_kernel<false>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+	const bool wide4 = p.kernel == MRT_KERNEL_LANE4_PERSISTENT && p.nodes4 != nullptr;
+	if (wide4) {
+		if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true, true>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+		else hipLaunchKernelGGL((trace_lane_persistent_kernel<false, true>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+	} else {
+		if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true, false>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+		else hipLaunchKernelGGL((trace_lane_persistent_kernel<false, false>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+	}
 	return hipGetLastError();
 }
 

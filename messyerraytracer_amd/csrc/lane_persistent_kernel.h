@@ -10,9 +10,25 @@
 //     their hits and hands them new rays (ballot + mbcnt prefix, one atomicAdd per refill);
 //   * keeps only the top `lds_depth` stack entries per lane in LDS ([depth][lane] layout)
 //     and spills deeper entries to a per-lane slice of an HBM scratch buffer, so LDS no
-//     longer limits occupancy (16 entries = 4 KB per wave -> 8 waves per SIMD).
-// The traversal itself is trace_lane_kernel's (same arithmetic, same tie rule).
+//     longer limits occupancy (16 entries = 4 KB per wave);
+//   * alternates a NODE phase and a LEAF phase under wave-uniform control: the node phase
+//     steps every lane that stands at an inner node and ends as soon as `leaf_wait` lanes
+//     stand at a leaf (or nobody is at an inner node); the leaf phase then intersects those
+//     leaves.  The plain while-while loop of trace_lane_kernel keeps a lane that reached its
+//     leaf waiting until the LAST lane of the wave has reached one: PMC counters put its node
+//     steps at 11 busy lanes of 64.  Node steps are 93 % of the arithmetic of a ray and leaf
+//     tests 7 %, so it pays to run the cheap leaf phase often, at low occupancy, to keep the
+//     expensive node phase dense.
+// The arithmetic is trace_lane_kernel's (same operations, same tie rule).
+//
+// WIDE4: the same walk over the 4-wide collapse of the BVH (Dev4Node, one 128-byte cache line
+// per node; tools/ubench/tcp_rate.hip: a divergent fetch is paid per cache line, so a 4-wide
+// node costs what a 2-wide node costs and a ray needs half as many).  Children are visited
+// nearest first (sorting network on packed distance|slot keys); the order never changes a
+// result.
 #pragma once
+
+#define MRT_RAY_CHUNK 256u // rays a wave reserves per atomic on the global counter
 
 struct PersistParams {
 	unsigned long long *next_ray; // global ray counter (zeroed before the launch)
@@ -20,12 +36,17 @@ struct PersistParams {
 	uint32_t overflow_stride;     // = total threads of the launch
 	uint32_t lds_depth;           // stack entries per lane kept in LDS
 	uint32_t refill;              // refill when at least this many lanes are idle
+	uint32_t leaf_wait;           // leave the node phase when this many lanes stand at a leaf
 };
 
-template <bool ANY_HIT>
-// (69 VGPRs = 7 waves per SIMD; forcing 8 with launch bounds spills and measured the same: the
-// kernel is bound by the divergent 64-byte node fetches, not by occupancy any more)
-__global__ __launch_bounds__(MRT_WG) void trace_lane_persistent_kernel(const TraceParams p, const PersistParams q)
+#ifdef MRT_PERSIST_WPE // experiment: ask the register allocator for at least this many waves per SIMD
+#define MRT_PERSIST_ATTR __attribute__((amdgpu_waves_per_eu(MRT_PERSIST_WPE, 8)))
+#else
+#define MRT_PERSIST_ATTR
+#endif
+
+template <bool ANY_HIT, bool WIDE4>
+__global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent_kernel(const TraceParams p, const PersistParams q)
 {
 	extern __shared__ uint32_t lds_stack[];
 	if (skip_launch(p)) return;
@@ -33,6 +54,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_persistent_kernel(const Tra
 	const uint32_t gtid = blockIdx.x * MRT_WG + threadIdx.x;
 	const uint32_t lds_base = wave * (q.lds_depth * MRT_WAVE) + lane;
 	const float4 *nodes = reinterpret_cast<const float4 *>(p.nodes);
+	const float4 *nodes4 = reinterpret_cast<const float4 *>(p.nodes4);
 	const float4 *hot = reinterpret_cast<const float4 *>(p.tri_hot);
 
 	// per-lane ray state
@@ -45,6 +67,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_persistent_kernel(const Tra
 	uint32_t depth = 0;
 	bool has_ray = false;
 	bool exhausted = false;   // wave-uniform: the ray counter ran past the batch
+	uint64_t range_next = 0, range_end = 0; // wave-uniform: rays this wave has reserved and not yet handed out
 
 	auto push = [&](uint32_t ref) {
 		if (depth < q.lds_depth) lds_stack[lds_base + depth * MRT_WAVE] = ref;
@@ -74,14 +97,26 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_persistent_kernel(const Tra
 		}
 		const unsigned long long idle_mask = __ballot(idle);
 		if (!exhausted && idle_mask != 0ull) {
+			// Rays come from a wave-private range [range_next, range_end) that is restocked MRT_RAY_CHUNK
+			// rays at a time from the global counter: one device-scope atomic on ONE address costs about
+			// 10 ns chip-wide, and one atomic per refill (a million of them at C4) was what bounded the kernel.
 			const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle_mask);
-			unsigned long long base = 0;
-			if (lane == (uint32_t)__builtin_ctzll(idle_mask)) base = atomicAdd(q.next_ray, (unsigned long long)n_idle);
-			base = __shfl(base, __builtin_ctzll(idle_mask));
-			if (base + n_idle >= p.count) exhausted = true; // the counter only grows: nothing left after this hand-out
+			const uint64_t avail = range_end - range_next; // wave-uniform
+			uint64_t fresh = 0;                            // start of a newly fetched chunk (if one is needed)
+			if (avail < n_idle) {
+				unsigned long long base = 0;
+				if (lane == (uint32_t)__builtin_ctzll(idle_mask)) base = atomicAdd(q.next_ray, (unsigned long long)MRT_RAY_CHUNK);
+				fresh = __shfl(base, __builtin_ctzll(idle_mask));
+			}
+			uint64_t g = p.count; // this lane's new ray (>= count: none)
 			if (idle) {
 				const uint32_t rank = (uint32_t)__builtin_popcountll(idle_mask & ((1ull << lane) - 1ull));
-				const uint64_t g = base + rank;
+				g = rank < avail ? range_next + rank : fresh + (rank - avail);
+			}
+			if (avail < n_idle) { range_next = fresh + (n_idle - avail); range_end = fresh + MRT_RAY_CHUNK; }
+			else range_next += n_idle;
+			if (range_next >= p.count) { range_next = range_end = 0; exhausted = true; } // the counter only grows
+			if (idle) {
 				if (g < p.count) {
 					ray_idx = p.perm ? (uint64_t)p.perm[g] : g;
 					load_ray(p, ray_idx, 0, 0, r);
@@ -101,30 +136,69 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_persistent_kernel(const Tra
 
 		// ---- traverse until enough lanes have finished to make a refill worthwhile ----
 		for (;;) {
-			while (cur < kSentinel) { // inner nodes: glsl:243-318
-				const float4 *n = nodes + (size_t)cur * 4u;
-				const float4 a = n[0], b = n[1], c = n[2], d = n[3];
-				const float l0x = fma_(a.x, ix, nrx), l1x = fma_(b.x, ix, nrx);
-				const float l0y = fma_(a.y, iy, nry), l1y = fma_(b.y, iy, nry);
-				const float l0z = fma_(a.z, iz, nrz), l1z = fma_(b.z, iz, nrz);
-				const float r0x = fma_(c.x, ix, nrx), r1x = fma_(d.x, ix, nrx);
-				const float r0y = fma_(c.y, iy, nry), r1y = fma_(d.y, iy, nry);
-				const float r0z = fma_(c.z, iz, nrz), r1z = fma_(d.z, iz, nrz);
-				const float tl = fmaxf(fmaxf(fminf(l0x, l1x), fminf(l0y, l1y)), fmaxf(fminf(l0z, l1z), r.t_min));
-				const float tlx = fminf(fminf(fmaxf(l0x, l1x), fmaxf(l0y, l1y)), fminf(fmaxf(l0z, l1z), best_t));
-				const float tr = fmaxf(fmaxf(fminf(r0x, r1x), fminf(r0y, r1y)), fmaxf(fminf(r0z, r1z), r.t_min));
-				const float trx = fminf(fminf(fmaxf(r0x, r1x), fmaxf(r0y, r1y)), fminf(fmaxf(r0z, r1z), best_t));
-				const bool hl = tl <= tlx, hr = tr <= trx;
-				const uint32_t lref = __float_as_uint(a.w), rref = __float_as_uint(b.w);
-				if (hl && hr) {
-					const bool left_near = tl < tr;
-					push(left_near ? rref : lref);
-					cur = left_near ? lref : rref;
-				} else if (hl) cur = lref;
-				else if (hr) cur = rref;
-				else cur = pop();
+			// NODE phase (wave-uniform loop, lanes at an inner node take the step)
+			while (__ballot(cur < kSentinel) != 0ull) {
+				if (WIDE4 && cur < kSentinel) { // 4-wide collapse: one 128-byte line per step
+					const float4 *n = nodes4 + (size_t)cur * 8u;
+					const float4 b0 = n[0], b1 = n[1], b2 = n[2], b3 = n[3], b4 = n[4], b5 = n[5], refs = n[6];
+					// child c box: min = (m[6c], m[6c+1], m[6c+2]), max = (m[6c+3], m[6c+4], m[6c+5])
+					const float m[24] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w,
+						b3.x, b3.y, b3.z, b3.w, b4.x, b4.y, b4.z, b4.w, b5.x, b5.y, b5.z, b5.w };
+					// finite upper bound: the point box at +inf of an unused child slot must fail `tnear <= tfar`
+					const float lim = fminf(best_t, FLT_MAX);
+					uint32_t key[4];
+#pragma unroll
+					for (int c = 0; c < 4; c++) {
+						const float x0 = fma_(m[6 * c], ix, nrx), x1 = fma_(m[6 * c + 3], ix, nrx);
+						const float y0 = fma_(m[6 * c + 1], iy, nry), y1 = fma_(m[6 * c + 4], iy, nry);
+						const float z0 = fma_(m[6 * c + 2], iz, nrz), z1 = fma_(m[6 * c + 5], iz, nrz);
+						const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), r.t_min));
+						const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim));
+						// key: entry distance (>= t_min >= 0: float order == unsigned order) with the slot in the
+						// low two bits; the order of the walk only affects speed, never the result (tie rule)
+						key[c] = tnear <= tfar ? ((__float_as_uint(tnear) & ~3u) | (uint32_t)c) : 0xFFFFFFFFu;
+					}
+#define MRT_CSWAP(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
+					MRT_CSWAP(0, 1) MRT_CSWAP(2, 3) MRT_CSWAP(0, 2) MRT_CSWAP(1, 3) MRT_CSWAP(1, 2)
+#undef MRT_CSWAP
+					if (key[0] == 0xFFFFFFFFu) cur = pop();
+					else {
+						const uint32_t r0 = __float_as_uint(refs.x), r1 = __float_as_uint(refs.y), r2 = __float_as_uint(refs.z), r3 = __float_as_uint(refs.w);
+						auto pick = [&](uint32_t k) { const uint32_t s = k & 3u; return s == 0u ? r0 : (s == 1u ? r1 : (s == 2u ? r2 : r3)); };
+						// farthest first, so the nearest pushed child is popped first
+						if (key[3] != 0xFFFFFFFFu) push(pick(key[3]));
+						if (key[2] != 0xFFFFFFFFu) push(pick(key[2]));
+						if (key[1] != 0xFFFFFFFFu) push(pick(key[1]));
+						cur = pick(key[0]);
+					}
+				}
+				if (!WIDE4 && cur < kSentinel) { // dual-AABB node: glsl:243-318
+					const float4 *n = nodes + (size_t)cur * 4u;
+					const float4 a = n[0], b = n[1], c = n[2], d = n[3];
+					const float l0x = fma_(a.x, ix, nrx), l1x = fma_(b.x, ix, nrx);
+					const float l0y = fma_(a.y, iy, nry), l1y = fma_(b.y, iy, nry);
+					const float l0z = fma_(a.z, iz, nrz), l1z = fma_(b.z, iz, nrz);
+					const float r0x = fma_(c.x, ix, nrx), r1x = fma_(d.x, ix, nrx);
+					const float r0y = fma_(c.y, iy, nry), r1y = fma_(d.y, iy, nry);
+					const float r0z = fma_(c.z, iz, nrz), r1z = fma_(d.z, iz, nrz);
+					const float tl = fmaxf(fmaxf(fminf(l0x, l1x), fminf(l0y, l1y)), fmaxf(fminf(l0z, l1z), r.t_min));
+					const float tlx = fminf(fminf(fmaxf(l0x, l1x), fmaxf(l0y, l1y)), fminf(fmaxf(l0z, l1z), best_t));
+					const float tr = fmaxf(fmaxf(fminf(r0x, r1x), fminf(r0y, r1y)), fmaxf(fminf(r0z, r1z), r.t_min));
+					const float trx = fminf(fminf(fmaxf(r0x, r1x), fmaxf(r0y, r1y)), fminf(fmaxf(r0z, r1z), best_t));
+					const bool hl = tl <= tlx, hr = tr <= trx;
+					const uint32_t lref = __float_as_uint(a.w), rref = __float_as_uint(b.w);
+					if (hl && hr) {
+						const bool left_near = tl < tr;
+						push(left_near ? rref : lref);
+						cur = left_near ? lref : rref;
+					} else if (hl) cur = lref;
+					else if (hr) cur = rref;
+					else cur = pop();
+				}
+				if ((uint32_t)__builtin_popcountll(__ballot(cur >= kLeafBit)) >= q.leaf_wait) break;
 			}
-			while (cur >= kLeafBit) { // leaves: glsl:166-192
+			// LEAF phase: every lane at a leaf intersects that leaf (glsl:166-192), then pops
+			if (cur >= kLeafBit) {
 				uint32_t slot = cur & 0x7FFFFFFFu;
 				bool last;
 				do {
@@ -158,8 +232,8 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_persistent_kernel(const Tra
 					}
 					slot++;
 				} while (!last);
-				if (ANY_HIT && best_slot != 0xFFFFFFFFu) { cur = kSentinel; depth = 0; break; }
-				cur = pop();
+				if (ANY_HIT && best_slot != 0xFFFFFFFFu) { cur = kSentinel; depth = 0; }
+				else cur = pop();
 			}
 			const unsigned long long busy = __ballot(cur != kSentinel);
 			if (busy == 0ull) break;

@@ -65,7 +65,18 @@ def incoherent_case(name, rounds, out):
                 ("persist16_r32", dict(kernel=capi.KERNEL_LANE_PERSISTENT, refill=32)),
                 ("persist24", dict(kernel=capi.KERNEL_LANE_PERSISTENT, stack_override=24)),
                 ("persist32", dict(kernel=capi.KERNEL_LANE_PERSISTENT, stack_override=32)),
+                ("wide4_16", dict(kernel=capi.KERNEL_LANE4_PERSISTENT)),
+                ("wide4_24", dict(kernel=capi.KERNEL_LANE4_PERSISTENT, stack_override=24)),
+                ("wide4_32", dict(kernel=capi.KERNEL_LANE4_PERSISTENT, stack_override=32)),
+                ("wide4_16_r32", dict(kernel=capi.KERNEL_LANE4_PERSISTENT, refill=32)),
+                *[(f"p2_l{lw}_r{rf}", dict(kernel=capi.KERNEL_LANE_PERSISTENT, leaf_wait=lw, refill=rf))
+                  for lw in (2, 4, 8, 16, 32, 64) for rf in (8, 16)],
+                *[(f"p4_l{lw}_r{rf}", dict(kernel=capi.KERNEL_LANE4_PERSISTENT, leaf_wait=lw, refill=rf))
+                  for lw in (2, 4, 8, 16, 32, 64) for rf in (8, 16)],
                 ("auto", dict())]
+    only = os.environ.get("MRT_BENCH_VARIANTS")  # comma-separated subset
+    if only:
+        variants = [v for v in variants if v[0] in only.split(",")]
     for kname, kw in variants:
         ctx = capi.Context(0, **kw)
         scene.upload(ctx)
