@@ -194,8 +194,9 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 		ovf = (uint32_t *)ctx->overflow.ptr;
 	}
 	p.kernel = wide4 ? MRT_KERNEL_LANE4_PERSISTENT : MRT_KERNEL_LANE_PERSISTENT;
-	unsigned long long *next_ray = ctx->d_counters + 12;
-	HIP_TRY(ctx, hipMemsetAsync(next_ray, 0, sizeof(unsigned long long), ctx->stream));
+	// eight ray counters (one per region of the batch), 128 bytes apart
+	unsigned long long *next_ray = ctx->d_counters + 16 + 1026;
+	HIP_TRY(ctx, hipMemsetAsync(next_ray, 0, 128 * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace_persistent(p, next_ray, ovf, lds_depth, ctx->opts.refill ? ctx->opts.refill : 16u,
 			ctx->opts.leaf_wait ? ctx->opts.leaf_wait : 16u, (uint32_t)blocks, any_hit, ctx->stream));
 	return MRT_OK;
@@ -345,8 +346,8 @@ int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
 	ctx->stream = ctx->own_stream;
 	for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) return bail(MRT_ERR_HIP);
 	// [0..7] visit counters, [8..15] detected grid, [16..1040] detect_grid_kernel scratch (masks + ticket)
-	if (hipMalloc(&ctx->d_counters, (16 + 1026) * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_OOM);
-	if (hipMemset(ctx->d_counters, 0, (16 + 1026) * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_HIP);
+	if (hipMalloc(&ctx->d_counters, (16 + 1026 + 128) * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_OOM);
+	if (hipMemset(ctx->d_counters, 0, (16 + 1026 + 128) * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_HIP);
 	*out = ctx;
 	return MRT_OK;
 }

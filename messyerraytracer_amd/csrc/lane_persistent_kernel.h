@@ -31,7 +31,7 @@
 #define MRT_RAY_CHUNK 256u // rays a wave reserves per atomic on the global counter
 
 struct PersistParams {
-	unsigned long long *next_ray; // global ray counter (zeroed before the launch)
+	unsigned long long *next_ray; // 8 ray counters, one per region of the batch, 16 u64 apart (zeroed before the launch)
 	uint32_t *overflow;           // [depth - lds_depth][global thread] spill area
 	uint32_t overflow_stride;     // = total threads of the launch
 	uint32_t lds_depth;           // stack entries per lane kept in LDS
@@ -68,6 +68,9 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 	bool has_ray = false;
 	bool exhausted = false;   // wave-uniform: the ray counter ran past the batch
 	uint64_t range_next = 0, range_end = 0; // wave-uniform: rays this wave has reserved and not yet handed out
+	uint32_t region, regions_tried = 0;     // wave-uniform: the region this wave draws from; regions found empty
+	asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(region)); // the XCD this wave runs on (speed only)
+	region &= 7u;
 
 	auto push = [&](uint32_t ref) {
 		if (depth < q.lds_depth) lds_stack[lds_base + depth * MRT_WAVE] = ref;
@@ -100,24 +103,40 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 			// Rays come from a wave-private range [range_next, range_end) that is restocked MRT_RAY_CHUNK
 			// rays at a time from the global counter: one device-scope atomic on ONE address costs about
 			// 10 ns chip-wide, and one atomic per refill (a million of them at C4) was what bounded the kernel.
+			// The batch is cut into 8 regions with one counter each, and a wave starts in the region of the
+			// XCD it runs on: with sorted rays an XCD then works on one part of the scene and its 4 MB L2
+			// keeps that part of the BVH (the eight L2s hold different nodes instead of the same ones).  A
+			// region that runs dry sends its waves to the next one, so the load still balances.
 			const uint32_t n_idle = (uint32_t)__builtin_popcountll(idle_mask);
 			const uint64_t avail = range_end - range_next; // wave-uniform
-			uint64_t fresh = 0;                            // start of a newly fetched chunk (if one is needed)
+			uint64_t fresh_lo = 0, fresh_hi = 0;           // a newly reserved chunk (if one is needed and left)
 			if (avail < n_idle) {
-				unsigned long long base = 0;
-				if (lane == (uint32_t)__builtin_ctzll(idle_mask)) base = atomicAdd(q.next_ray, (unsigned long long)MRT_RAY_CHUNK);
-				fresh = __shfl(base, __builtin_ctzll(idle_mask));
+				while (regions_tried < 8u) {
+					const uint64_t lo = p.count * region / 8u, hi = p.count * (region + 1u) / 8u;
+					unsigned long long base = 0;
+					if (lane == (uint32_t)__builtin_ctzll(idle_mask)) base = atomicAdd(q.next_ray + region * 16u, (unsigned long long)MRT_RAY_CHUNK);
+					base = __shfl(base, __builtin_ctzll(idle_mask));
+					if (lo + base < hi) {
+						fresh_lo = lo + base;
+						fresh_hi = fresh_lo + MRT_RAY_CHUNK < hi ? fresh_lo + MRT_RAY_CHUNK : hi;
+						break;
+					}
+					region = (region + 1u) & 7u; regions_tried++; // this region is handed out completely
+				}
 			}
-			uint64_t g = p.count; // this lane's new ray (>= count: none)
+			uint64_t g = ~0ull; // this lane's new ray (none)
 			if (idle) {
 				const uint32_t rank = (uint32_t)__builtin_popcountll(idle_mask & ((1ull << lane) - 1ull));
-				g = rank < avail ? range_next + rank : fresh + (rank - avail);
+				if (rank < avail) g = range_next + rank;
+				else if (fresh_lo + (rank - avail) < fresh_hi) g = fresh_lo + (rank - avail);
 			}
-			if (avail < n_idle) { range_next = fresh + (n_idle - avail); range_end = fresh + MRT_RAY_CHUNK; }
-			else range_next += n_idle;
-			if (range_next >= p.count) { range_next = range_end = 0; exhausted = true; } // the counter only grows
+			if (avail < n_idle) {
+				const uint64_t want = n_idle - avail, got = fresh_hi - fresh_lo;
+				range_next = fresh_lo + (want < got ? want : got); range_end = fresh_hi;
+				if (regions_tried == 8u) exhausted = true; // every region is handed out: no lane will get a ray again
+			} else range_next += n_idle;
 			if (idle) {
-				if (g < p.count) {
+				if (g != ~0ull) {
 					ray_idx = p.perm ? (uint64_t)p.perm[g] : g;
 					load_ray(p, ray_idx, 0, 0, r);
 					has_ray = true;
