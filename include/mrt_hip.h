@@ -138,6 +138,8 @@ typedef struct mrt_stats {
 	uint64_t dead_pops;          /* count_visits, packet kernel: popped nodes no lane still needed */
 	uint32_t detected_grid_w;    /* count_visits: row width found for the last coherent mrt_cast (0 = none) */
 	uint32_t reserved;           /* count_visits: 1 if the last batch declared coherent was judged incoherent on the device */
+	float last_build_ms;         /* device time of the last mrt_build_scene_device */
+	uint32_t reserved2;
 } mrt_stats;
 
 /* mode: RayQuery::Mode, src/api/ray_query.h:54-57 / RAY_MODE spec constant,
@@ -234,6 +236,16 @@ int mrt_bvh2_build(const float *verts4, uint32_t n_tris, mrt_bvh_node32 *nodes,
  * used_nodes (item 2).  Drains a pending async dispatch first (cpp:198-202). */
 int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 		const mrt_bvh_node32 *nodes, uint32_t used_nodes, const uint32_t *prim_idx);
+/* ---- build on the device: RayTracerServer::build (src/godot/raytracer_server.cpp:161-181 =
+ * RayScene::build + upload_scene) for scenes that change too often to pay the host builder
+ * (1.3 s per million triangles).  An LBVH (Morton sort + Karras radix tree, one triangle per
+ * leaf) is built from the triangles in milliseconds, directly in device layout; casts return
+ * exactly what they return against the host-built tree (results do not depend on which valid BVH
+ * is walked) but walk more nodes per ray.  tris: host array, or device array with
+ * MRT_BUILD_TRIS_ON_DEVICE.  mrt_stats.last_build_ms = device time of the build.
+ * MRT_ERR_UNSUPPORTED if the tree comes out deeper than the traversal stack (build on the host). */
+enum { MRT_BUILD_TRIS_ON_DEVICE = 1u << 0 };
+int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris, uint32_t flags);
 int mrt_is_available(const mrt_ctx *ctx);      /* initialized && scene uploaded */
 int mrt_scene_info(const mrt_ctx *ctx, uint32_t *n_tris, uint32_t *n_wide_nodes, uint32_t *bvh_depth);
 

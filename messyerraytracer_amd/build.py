@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmrt_hip.so")
 HOST_TEST = os.path.join(HERE, "host_mirror_test")
 
-SOURCES = ["kernels.hip", "api.hip", "host/scene_prep.cpp", "host/bvh_builder.cpp"]
+SOURCES = ["kernels.hip", "api.hip", "device_build.hip", "host/scene_prep.cpp", "host/bvh_builder.cpp"]
 HEADERS = ["mrt_internal.h", "packet_kernel.h", "packet4_kernel.h", "packet2_kernel.h", "packet_asm_kernel.h", "lane_persistent_kernel.h", "../../include/mrt_hip.h", "host/gpu_ray_caster.hpp", "host/ray_dispatcher.hpp",
            "host/host_types.hpp"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall",

@@ -19,6 +19,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SCENE, ERR_PENDING, ERR_NOT_PENDING,
 MODE_NEAREST, MODE_ANY_HIT = 0, 1
 FLAG_COHERENT, FLAG_RAYS_ON_DEVICE, FLAG_HITS_ON_DEVICE, FLAG_HOST_LAYOUT, FLAG_BOOL_OUT, FLAG_FORCE_SORT, FLAG_TOKEN_OUT, FLAG_ASYNC = (1 << i for i in range(8))
 TOKEN_MISS = 0xFFFFFFFF
+BUILD_TRIS_ON_DEVICE = 1
 KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET, KERNEL_PACKET4, KERNEL_PACKET2, KERNEL_PACKET_ASM, KERNEL_LANE_PERSISTENT, \
     KERNEL_LANE4_PERSISTENT = range(8)
 
@@ -26,7 +27,7 @@ KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET, KERNEL_PACKET4, KERNEL_PACKET2, KERNEL_
 SYMBOLS = [
     "mrt_create", "mrt_destroy", "mrt_last_error", "mrt_status_string", "mrt_version", "mrt_set_stream",
     "mrt_synchronize", "mrt_make_triangles", "mrt_pack_host_triangles", "mrt_bvh2_build", "mrt_upload_scene",
-    "mrt_is_available", "mrt_scene_info", "mrt_cast", "mrt_submit", "mrt_collect", "mrt_has_pending",
+    "mrt_build_scene_device", "mrt_is_available", "mrt_scene_info", "mrt_cast", "mrt_submit", "mrt_collect", "mrt_has_pending",
     "mrt_camera_look", "mrt_generate_grid", "mrt_cast_grid", "mrt_cast_tiled", "mrt_expand_tokens",
     "mrt_expand_grid_tokens", "mrt_morton_keys",
     "mrt_get_stats", "mrt_device_alloc", "mrt_device_free", "mrt_memcpy_h2d", "mrt_memcpy_d2h",
@@ -56,7 +57,8 @@ class Stats(C.Structure):
     _fields_ = [("rays_cast", C.c_uint64), ("tri_tests", C.c_uint64), ("bvh_nodes_visited", C.c_uint64),
                 ("hits", C.c_uint64), ("last_trace_ms", C.c_float), ("last_sort_ms", C.c_float),
                 ("last_h2d_ms", C.c_float), ("last_d2h_ms", C.c_float), ("last_kernel_launches", C.c_uint32),
-                ("max_stack_depth", C.c_uint32), ("dead_pops", C.c_uint64), ("detected_grid_w", C.c_uint32), ("reserved", C.c_uint32)]
+                ("max_stack_depth", C.c_uint32), ("dead_pops", C.c_uint64), ("detected_grid_w", C.c_uint32), ("reserved", C.c_uint32),
+                ("last_build_ms", C.c_float), ("reserved2", C.c_uint32)]
 
 
 _lib = None
@@ -84,6 +86,7 @@ def load():
     L.mrt_pack_host_triangles.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.mrt_bvh2_build.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
     L.mrt_upload_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.mrt_build_scene_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
     L.mrt_is_available.argtypes = [C.c_void_p]
     L.mrt_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.mrt_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32]
@@ -204,6 +207,14 @@ class Context:
 
     def synchronize(self):
         self._chk(self.L.mrt_synchronize(self.h))
+
+    def build_scene_device(self, tris, n_tris=None, on_device=False):
+        """LBVH built on the device from mrt_tri64 triangles (numpy array, or a device pointer with on_device)."""
+        if isinstance(tris, np.ndarray):
+            tris = np.ascontiguousarray(tris)
+            assert tris.dtype == T.TRI64
+            n_tris = tris.shape[0]
+        self._chk(self.L.mrt_build_scene_device(self.h, _ptr(tris), n_tris, BUILD_TRIS_ON_DEVICE if on_device else 0))
 
     def upload_scene(self, tris, nodes, prim_idx):
         tris = np.ascontiguousarray(tris)

@@ -132,6 +132,7 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 // primary-ray grids), one lane per ray for everything else (sorted / incoherent batches).
 uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent)
 {
+	if (ctx->opts.kernel == MRT_KERNEL_PACKET4 && !ctx->d_nodes4) return MRT_KERNEL_PACKET; // device-built scenes have no 4-wide layout
 	if (ctx->opts.kernel >= MRT_KERNEL_LANE && ctx->opts.kernel <= MRT_KERNEL_LANE4_PERSISTENT) return ctx->opts.kernel;
 	// (PACKET4 halves the fetch chain but measured 7 % slower at C3: the walk is bound by
 	// instruction issue, and ordering four children costs more scalar work than it saves)
@@ -420,6 +421,59 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	// LDS stack entries per lane: what this BVH can need, rounded up to 8, at most 64.
 	ctx->stack_depth = ((h.depth + 7u) / 8u) * 8u;
 	if (ctx->stack_depth < 8) ctx->stack_depth = 8;
+	ctx->scene = true;
+	return MRT_OK;
+}
+
+int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris, uint32_t flags)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	if (!tris || n_tris == 0) return fail(ctx, MRT_ERR_INVALID, "build_scene_device: no triangles");
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	int rc = drain_pending(ctx);
+	if (rc) return rc;
+	const bool on_device = (flags & MRT_BUILD_TRIS_ON_DEVICE) != 0;
+	if (n_tris < 2) {
+		// a one-triangle scene has no radix tree: the host path wraps the root leaf (scene_prep.cpp)
+		mrt_tri64 t;
+		if (on_device) HIP_TRY(ctx, hipMemcpy(&t, tris, sizeof(t), hipMemcpyDeviceToHost)); else t = tris[0];
+		float verts[12] = { t.v0[0], t.v0[1], t.v0[2], 0.0f, t.v0[0] + t.edge1[0], t.v0[1] + t.edge1[1], t.v0[2] + t.edge1[2], 0.0f,
+			t.v0[0] + t.edge2[0], t.v0[1] + t.edge2[1], t.v0[2] + t.edge2[2], 0.0f };
+		mrt_bvh_node32 nodes[2]; uint32_t prim = 0, used = 0;
+		if ((rc = mrt_bvh2_build(verts, 1, nodes, &prim, &used, 1))) return fail(ctx, rc, "build_scene_device: host build failed");
+		return mrt_upload_scene(ctx, &t, 1, nodes, used, &prim);
+	}
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	hipEvent_t e0 = ctx->ev[0], e1 = ctx->ev[1];
+	HIP_TRY(ctx, hipEventRecord(e0, ctx->stream));
+	const mrt_tri64 *d_tris = tris;
+	void *staged = nullptr;
+	if (!on_device) {
+		if (hipMalloc(&staged, (size_t)n_tris * sizeof(mrt_tri64)) != hipSuccess) return fail(ctx, MRT_ERR_OOM, "scene does not fit in device memory");
+		hipError_t e = hipMemcpyAsync(staged, tris, (size_t)n_tris * sizeof(mrt_tri64), hipMemcpyHostToDevice, ctx->stream);
+		if (e != hipSuccess) { (void)hipFree(staged); return fail(ctx, MRT_ERR_HIP, hipGetErrorString(e)); }
+		d_tris = (const mrt_tri64 *)staged;
+	}
+	mrt::DeviceBuildResult b;
+	rc = mrt::device_build_lbvh(d_tris, n_tris, (void *)ctx->stream, &b, ctx->err, sizeof(ctx->err));
+	if (staged) (void)hipFree(staged);
+	if (rc) return rc;
+	if (b.depth > 64) { // the packet kernels keep 64 stack entries per wave
+		(void)hipFree(b.nodes); (void)hipFree(b.hot); (void)hipFree(b.cold);
+		return fail(ctx, MRT_ERR_UNSUPPORTED, "device-built BVH deeper than the 64-entry traversal stack: build on the host");
+	}
+	HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
+	HIP_TRY(ctx, hipEventSynchronize(e1));
+	float ms = 0.0f;
+	HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+	free_scene(ctx);
+	ctx->d_nodes = b.nodes; ctx->d_hot = b.hot; ctx->d_cold = b.cold;
+	ctx->d_nodes4 = nullptr; ctx->n_nodes4 = 0; ctx->stack4 = 0; // no 4-wide collapse of a device-built tree (yet)
+	ctx->n_nodes = b.n_nodes; ctx->n_tris = b.n_tris; ctx->depth = b.depth;
+	for (int c = 0; c < 3; c++) { ctx->bounds_lo[c] = b.bounds_lo[c]; ctx->bounds_hi[c] = b.bounds_hi[c]; }
+	ctx->stack_depth = ((b.depth + 7u) / 8u) * 8u;
+	if (ctx->stack_depth < 8) ctx->stack_depth = 8;
+	ctx->stats.last_build_ms = ms;
 	ctx->scene = true;
 	return MRT_OK;
 }

@@ -1,0 +1,269 @@
+// device_build.hip — builds the acceleration structure on the device (mrt_build_scene_device).
+//
+// The reference builds its BVH on the host (tinybvh::BVH::Build under RayScene::build,
+// src/accel/ray_scene.h:62-86: 1.3 s for 1 M triangles on 8 cores, 10-15 s for 10 M) and
+// uploads it (GPURayCaster::upload_scene, src/gpu/gpu_ray_caster.cpp:193-341); a scene that
+// changes every frame cannot pay that.  This file is the device-side alternative (SURVEY.md
+// 8(f) rank 4): an LBVH —
+//   1. triangle boxes + scene bounds            (lbvh_bounds_kernel)
+//   2. 63-bit Morton key of every box centre    (lbvh_keys_kernel)
+//   3. radix sort of (key, triangle) pairs      (rocPRIM)
+//   4. the binary radix tree over the keys      (lbvh_hierarchy_kernel; Karras 2012, "Maximizing
+//      Parallelism in the Construction of BVHs, Octrees, and k-d Trees", sections 3-4)
+//   5. boxes bottom-up, emitting DevNode rows   (lbvh_fit_kernel; one thread per leaf climbs, the
+//      second thread to reach a node owns it)
+//   6. leaf-ordered TriHot / TriCold rows       (lbvh_leaves_kernel)
+// written straight into the layout the trace kernels read (mrt_internal.h).  One triangle per leaf.
+// The tree is a valid BVH over the same triangles, so by the tie rule ("Arithmetic")
+// casts against it return what casts against the host-built SAH tree return; it is a worse tree
+// (more node visits per ray), which is the price of building it in milliseconds.
+#include <cfloat>
+#include <cstdio>
+#include <cstring>
+#include <string.h> // before rocprim: its texture_cache_iterator.hpp calls ::memset
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+#include "mrt_internal.h"
+
+namespace mrt {
+
+namespace {
+
+#define LBVH_WG 256
+
+struct Box { float mn[3], mx[3]; };
+
+// order-preserving float <-> uint (for atomicMin / atomicMax on floats of either sign)
+__device__ __forceinline__ uint32_t f2ord(float f) { const uint32_t u = __float_as_uint(f); return (u & 0x80000000u) ? ~u : (u | 0x80000000u); }
+__host__ __device__ __forceinline__ float ord2f(uint32_t o) {
+	const uint32_t u = (o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o;
+	float f; memcpy(&f, &u, 4); return f;
+}
+
+// One ulp outwards: v0 + e1 is a rounded sum, the true vertex may lie half an ulp outside it.
+__device__ __forceinline__ float ulp_down(float f) { return f == 0.0f ? -FLT_MIN : __uint_as_float(__float_as_uint(f) + (f > 0.0f ? -1 : 1)); }
+__device__ __forceinline__ float ulp_up(float f) { return f == 0.0f ? FLT_MIN : __uint_as_float(__float_as_uint(f) + (f > 0.0f ? 1 : -1)); }
+
+// 1. box of every triangle (vertices v0, v0+e1, v0+e2 as the intersection test sees them) and the
+//    bounds of all boxes: bounds[0..2] = min (ordered uint), bounds[3..5] = max.
+__global__ __launch_bounds__(LBVH_WG) void lbvh_bounds_kernel(const mrt_tri64 *tris, uint32_t n, Box *boxes, uint32_t *bounds)
+{
+	const uint32_t i = blockIdx.x * LBVH_WG + threadIdx.x;
+	float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
+	if (i < n) {
+		const float4 *t = reinterpret_cast<const float4 *>(tris + i);
+		const float4 a = t[0], b = t[1], c = t[2];
+		const float v0[3] = { a.x, a.y, a.z }, e1[3] = { b.x, b.y, b.z }, e2[3] = { c.x, c.y, c.z };
+		Box bx;
+		for (int k = 0; k < 3; k++) {
+			const float p1 = v0[k] + e1[k], p2 = v0[k] + e2[k];
+			mn[k] = ulp_down(fminf(v0[k], fminf(p1, p2)));
+			mx[k] = ulp_up(fmaxf(v0[k], fmaxf(p1, p2)));
+			bx.mn[k] = mn[k]; bx.mx[k] = mx[k];
+		}
+		boxes[i] = bx;
+	}
+	// wave reduction, one atomic per wave and component
+	for (int k = 0; k < 3; k++) {
+		float lo = mn[k], hi = mx[k];
+		for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
+		if ((threadIdx.x & 63u) == 0u) { atomicMin(&bounds[k], f2ord(lo)); atomicMax(&bounds[3 + k], f2ord(hi)); }
+	}
+}
+
+__device__ __forceinline__ uint64_t spread21(uint32_t v)
+{
+	uint64_t x = v & 0x1FFFFFu;
+	x = (x | x << 32) & 0x1F00000000FFFFull;
+	x = (x | x << 16) & 0x1F0000FF0000FFull;
+	x = (x | x << 8) & 0x100F00F00F00F00Full;
+	x = (x | x << 4) & 0x10C30C30C30C30C3ull;
+	x = (x | x << 2) & 0x1249249249249249ull;
+	return x;
+}
+
+// 2. key = 63-bit Morton code of the box centre on a 2^21 grid over the scene bounds
+__global__ __launch_bounds__(LBVH_WG) void lbvh_keys_kernel(const Box *boxes, uint32_t n, const uint32_t *bounds, uint64_t *keys, uint32_t *index)
+{
+	const uint32_t i = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (i >= n) return;
+	const Box b = boxes[i];
+	uint32_t q[3];
+	for (int k = 0; k < 3; k++) {
+		const float lo = ord2f(bounds[k]), hi = ord2f(bounds[3 + k]);
+		const float ext = hi - lo;
+		const float c = 0.5f * b.mn[k] + 0.5f * b.mx[k];
+		float u = ext > 0.0f ? (c - lo) / ext : 0.0f;
+		u = fminf(fmaxf(u, 0.0f), 1.0f);
+		const uint32_t g = (uint32_t)(u * 2097151.0f);
+		q[k] = g > 2097151u ? 2097151u : g;
+	}
+	keys[i] = spread21(q[0]) | (spread21(q[1]) << 1) | (spread21(q[2]) << 2);
+	index[i] = i;
+}
+
+// length of the common prefix of the keys at sorted positions i and j (equal keys: the positions
+// themselves break the tie, so every leaf has a distinct code); -1 outside the array
+__device__ __forceinline__ int lbvh_delta(const uint64_t *keys, int64_t n, int64_t i, int64_t j)
+{
+	if (j < 0 || j >= n) return -1;
+	const uint64_t a = keys[i], b = keys[j];
+	if (a != b) return __builtin_clzll(a ^ b);
+	return 64 + __builtin_clz((uint32_t)i ^ (uint32_t)j);
+}
+
+// 4. Karras 2012, figure 4: internal node i covers the sorted leaves [min(i,j), max(i,j)] and splits
+//    after position gamma.  child refs: < n-1 internal node, kLeafBit | position for a leaf.
+__global__ __launch_bounds__(LBVH_WG) void lbvh_hierarchy_kernel(const uint64_t *keys, uint32_t n,
+		uint32_t *left, uint32_t *right, uint32_t *parent_of_node, uint32_t *parent_of_leaf)
+{
+	const int64_t i = (int64_t)blockIdx.x * LBVH_WG + threadIdx.x;
+	const int64_t nn = n;
+	if (i >= nn - 1) return;
+	const int d = lbvh_delta(keys, nn, i, i + 1) - lbvh_delta(keys, nn, i, i - 1) > 0 ? 1 : -1;
+	const int dmin = lbvh_delta(keys, nn, i, i - d);
+	int64_t lmax = 2;
+	while (lbvh_delta(keys, nn, i, i + lmax * d) > dmin) lmax *= 2;
+	int64_t l = 0;
+	for (int64_t t = lmax / 2; t >= 1; t /= 2)
+		if (lbvh_delta(keys, nn, i, i + (l + t) * d) > dmin) l += t;
+	const int64_t j = i + l * d;
+	const int dnode = lbvh_delta(keys, nn, i, j);
+	int64_t s = 0, t = l;
+	do {
+		t = (t + 1) / 2;
+		if (lbvh_delta(keys, nn, i, i + (s + t) * d) > dnode) s += t;
+	} while (t > 1);
+	const int64_t gamma = i + s * d + (d < 0 ? -1 : 0);
+	const int64_t lo = i < j ? i : j, hi = i < j ? j : i;
+	if (lo == gamma) { left[i] = kLeafBit | (uint32_t)gamma; parent_of_leaf[gamma] = (uint32_t)i; }
+	else { left[i] = (uint32_t)gamma; parent_of_node[gamma] = (uint32_t)i; }
+	if (hi == gamma + 1) { right[i] = kLeafBit | (uint32_t)(gamma + 1); parent_of_leaf[gamma + 1] = (uint32_t)i; }
+	else { right[i] = (uint32_t)(gamma + 1); parent_of_node[gamma + 1] = (uint32_t)i; }
+	if (i == 0) parent_of_node[0] = 0xFFFFFFFFu;
+}
+
+// 5. One thread per leaf climbs towards the root.  The first thread to reach a node leaves (its
+//    sibling subtree is not finished); the second owns the node: both child boxes are final, it
+//    writes the DevNode row and the node's own box and climbs on.  The hand-off between the two
+//    threads (any two CUs, any two XCDs) is the agent-scope acquire-release counter.
+__global__ __launch_bounds__(LBVH_WG) void lbvh_fit_kernel(uint32_t n, const Box *tri_boxes, const uint32_t *sorted_tri,
+		const uint32_t *left, const uint32_t *right, const uint32_t *parent_of_node, const uint32_t *parent_of_leaf,
+		uint32_t *arrivals, Box *node_box, uint32_t *node_depth, DevNode *nodes, uint32_t *max_depth)
+{
+	const uint32_t leaf = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (leaf >= n) return;
+	uint32_t node = parent_of_leaf[leaf];
+	for (;;) {
+		const uint32_t before = __hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		if (before == 0u) return;
+		const uint32_t l = left[node], r = right[node];
+		const Box lb = (l & kLeafBit) ? tri_boxes[sorted_tri[l & 0x7FFFFFFFu]] : node_box[l];
+		const Box rb = (r & kLeafBit) ? tri_boxes[sorted_tri[r & 0x7FFFFFFFu]] : node_box[r];
+		const uint32_t dl = (l & kLeafBit) ? 0u : node_depth[l], dr = (r & kLeafBit) ? 0u : node_depth[r];
+		DevNode g;
+		Box u;
+		for (int k = 0; k < 3; k++) {
+			g.lmin[k] = lb.mn[k]; g.lmax[k] = lb.mx[k]; g.rmin[k] = rb.mn[k]; g.rmax[k] = rb.mx[k];
+			u.mn[k] = fminf(lb.mn[k], rb.mn[k]); u.mx[k] = fmaxf(lb.mx[k], rb.mx[k]);
+		}
+		g.left_ref = l; g.right_ref = r;
+		g.left_count = (l & kLeafBit) ? 1u : 0u; g.right_count = (r & kLeafBit) ? 1u : 0u;
+		nodes[node] = g;
+		node_box[node] = u;
+		const uint32_t depth = (dl > dr ? dl : dr) + 1u;
+		node_depth[node] = depth;
+		if (node == 0u) { *max_depth = depth; return; }
+		node = parent_of_node[node];
+	}
+}
+
+// 6. triangle rows in leaf order (sorted position = slot); every leaf holds one triangle
+__global__ __launch_bounds__(LBVH_WG) void lbvh_leaves_kernel(const mrt_tri64 *tris, uint32_t n, const uint32_t *sorted_tri, TriHot *hot, TriCold *cold)
+{
+	const uint32_t slot = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (slot >= n) return;
+	const float4 *t = reinterpret_cast<const float4 *>(tris + sorted_tri[slot]);
+	const float4 a = t[0], b = t[1], c = t[2], d = t[3];
+	float4 *h = reinterpret_cast<float4 *>(hot + slot);
+	h[0] = a; h[1] = b;
+	float4 c2 = c; c2.w = __uint_as_float(kLastInLeaf);
+	h[2] = c2;
+	float4 nn = d; nn.w = 0.0f;
+	reinterpret_cast<float4 *>(cold)[slot] = nn;
+}
+
+} // namespace
+
+#define DB_TRY(call)                                                                                     \
+	do {                                                                                                 \
+		hipError_t e_ = (call);                                                                          \
+		if (e_ != hipSuccess) {                                                                          \
+			std::snprintf(err, err_len, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+			cleanup();                                                                                   \
+			return MRT_ERR_HIP;                                                                          \
+		}                                                                                                \
+	} while (0)
+
+// Builds nodes / hot / cold (hipMalloc'ed, owned by the caller on success) for the n >= 2 triangles
+// at d_tris (device).  depth = stack entries a traversal can need (incl. the sentinel).
+int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, void *stream_, DeviceBuildResult *out, char *err, size_t err_len)
+{
+	hipStream_t stream = (hipStream_t)stream_;
+	void *tmp[16] = {}; int n_tmp = 0;
+	DevNode *nodes = nullptr; TriHot *hot = nullptr; TriCold *cold = nullptr;
+	auto cleanup = [&] {
+		for (int i = 0; i < n_tmp; i++) if (tmp[i]) (void)hipFree(tmp[i]);
+		if (nodes) (void)hipFree(nodes);
+		if (hot) (void)hipFree(hot);
+		if (cold) (void)hipFree(cold);
+	};
+	auto alloc = [&](size_t bytes) -> void * {
+		void *p = nullptr;
+		if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
+		tmp[n_tmp++] = p;
+		return p;
+	};
+	const size_t nn = n;
+	Box *boxes = (Box *)alloc(nn * sizeof(Box));
+	uint32_t *scal = (uint32_t *)alloc(8 * sizeof(uint32_t)); // bounds[6], max_depth, pad
+	uint64_t *keys_a = (uint64_t *)alloc(nn * 8), *keys_b = (uint64_t *)alloc(nn * 8);
+	uint32_t *idx_a = (uint32_t *)alloc(nn * 4), *idx_b = (uint32_t *)alloc(nn * 4);
+	uint32_t *left = (uint32_t *)alloc(nn * 4), *right = (uint32_t *)alloc(nn * 4);
+	uint32_t *par_node = (uint32_t *)alloc(nn * 4), *par_leaf = (uint32_t *)alloc(nn * 4);
+	uint32_t *arrivals = (uint32_t *)alloc(nn * 4), *node_depth = (uint32_t *)alloc(nn * 4);
+	Box *node_box = (Box *)alloc(nn * sizeof(Box));
+	bool ok = boxes && scal && keys_a && keys_b && idx_a && idx_b && left && right && par_node && par_leaf && arrivals && node_depth && node_box;
+	ok = ok && hipMalloc(&nodes, (nn - 1) * sizeof(DevNode)) == hipSuccess && hipMalloc(&hot, nn * sizeof(TriHot) + 16) == hipSuccess &&
+			hipMalloc(&cold, nn * sizeof(TriCold)) == hipSuccess;
+	if (!ok) { std::snprintf(err, err_len, "device build: out of device memory"); cleanup(); return MRT_ERR_OOM; }
+
+	const uint32_t blocks = (uint32_t)((nn + LBVH_WG - 1) / LBVH_WG);
+	const uint32_t init[8] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u };
+	DB_TRY(hipMemcpyAsync(scal, init, sizeof(init), hipMemcpyHostToDevice, stream));
+	DB_TRY(hipMemsetAsync(arrivals, 0, nn * 4, stream));
+	hipLaunchKernelGGL(lbvh_bounds_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, d_tris, n, boxes, scal);
+	hipLaunchKernelGGL(lbvh_keys_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, boxes, n, scal, keys_a, idx_a);
+	size_t sort_bytes = 0;
+	DB_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_a, keys_b, idx_a, idx_b, nn, 0, 63, stream));
+	void *sort_tmp = alloc(sort_bytes);
+	if (!sort_tmp) { std::snprintf(err, err_len, "device build: out of device memory"); cleanup(); return MRT_ERR_OOM; }
+	DB_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys_a, keys_b, idx_a, idx_b, nn, 0, 63, stream));
+	hipLaunchKernelGGL(lbvh_hierarchy_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, keys_b, n, left, right, par_node, par_leaf);
+	hipLaunchKernelGGL(lbvh_fit_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, n, boxes, idx_b, left, right, par_node, par_leaf,
+			arrivals, node_box, node_depth, nodes, scal + 6);
+	hipLaunchKernelGGL(lbvh_leaves_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, d_tris, n, idx_b, hot, cold);
+	DB_TRY(hipGetLastError());
+	uint32_t h[8];
+	DB_TRY(hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, stream));
+	DB_TRY(hipStreamSynchronize(stream));
+	for (int i = 0; i < n_tmp; i++) (void)hipFree(tmp[i]);
+	n_tmp = 0;
+	out->nodes = nodes; out->hot = hot; out->cold = cold;
+	out->n_nodes = n - 1; out->n_tris = n;
+	out->depth = h[6] + 1u; // pending entries on the deepest path + the sentinel
+	for (int k = 0; k < 3; k++) { out->bounds_lo[k] = ord2f(h[k]); out->bounds_hi[k] = ord2f(h[3 + k]); }
+	return MRT_OK;
+}
+
+} // namespace mrt

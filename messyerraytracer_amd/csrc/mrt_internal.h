@@ -102,4 +102,13 @@ struct DeviceSceneHost {
 int prepare_scene(const mrt_tri64 *tris, uint32_t n_tris, const mrt_bvh_node32 *nodes, uint32_t used_nodes,
 		const uint32_t *prim_idx, DeviceSceneHost *out, char *err, size_t err_len);
 
+// device-side build (device_build.hip): LBVH over n >= 2 device-resident triangles, written in the
+// layout above.  Arrays are hipMalloc'ed and belong to the caller on success.  `stream` is a hipStream_t.
+struct DeviceBuildResult {
+	DevNode *nodes = nullptr; TriHot *hot = nullptr; TriCold *cold = nullptr;
+	uint32_t n_nodes = 0, n_tris = 0, depth = 0;
+	float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
+};
+int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, void *stream, DeviceBuildResult *out, char *err, size_t err_len);
+
 } // namespace mrt

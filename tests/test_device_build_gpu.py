@@ -1,0 +1,115 @@
+"""mrt_build_scene_device: the acceleration structure built on the device (LBVH) must give the
+hits the oracle gives on its host-built SAH tree — results do not depend on which valid BVH is
+walked (exact ties go to the lower triangle id), so the comparison is bit-exact."""
+import numpy as np
+import pytest
+
+from messyerraytracer_amd import capi, synth, types as T
+from oracle import pyoracle as po
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _rays(seed):
+    grid = po.grid_rays((0, 0, -12), (0, 0, 1), 100, 70, 50.0)
+    inc = synth.incoherent_rays(5000, seed)
+    inc["t_min"][:200] = 3.0
+    inc["t_max"][:200] = 3.0          # degenerate
+    inc["direction"][200:400] = [0, 1, 0]
+    inc["t_max"][400:700] = 1.5
+    return grid, inc
+
+
+def _check(c, osc, name, masks=(0xFFFFFFFF,)):
+    grid, inc = _rays(11)
+    for rays, kind in ((grid, "grid"), (inc, "incoherent")):
+        for mask in masks:
+            want = osc.trace(rays, query_mask=mask)
+            for flags in (capi.FLAG_COHERENT, 0):
+                parity.assert_exact(c.cast(rays, query_mask=mask, flags=flags), want, f"{name} {kind} mask={mask:#x} flags={flags}")
+            b = c.cast(rays, query_mask=mask, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT)
+            assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
+    cam = capi.camera_look((0, 0, -12), (0, 0, 1), 100, 70, 50.0)
+    parity.assert_exact(c.cast_grid(cam, 100, 70), osc.trace(grid), f"{name} cast_grid")
+
+
+@pytest.mark.parametrize("n_tris,scale,seed", [(1, 2.0, 5), (2, 2.0, 6), (3, 1.5, 7), (17, 1.0, 8), (1000, 0.5, 1), (20000, 0.25, 33)])
+def test_device_built_tree_gives_the_oracles_hits(built, n_tris, scale, seed):
+    v = synth.soup(n_tris, scale, seed)
+    layers = (1 << (np.arange(n_tris) % 3)).astype(np.uint32)
+    tris = capi.make_triangles(v, None, layers)
+    c = capi.Context(0)
+    c.build_scene_device(tris)
+    assert c.is_available() and c.scene_info()["n_tris"] == n_tris
+    _check(c, po.OracleScene(v, None, layers), f"n={n_tris}", masks=(0xFFFFFFFF, 0x5))
+    c.close()
+
+
+@pytest.mark.parametrize("kernel", [capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET4, capi.KERNEL_PACKET2,
+                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT])
+def test_every_kernel_walks_a_device_built_tree(built, kernel):
+    """Kernels that want the 4-wide layout (absent for device-built trees) must fall back, not fault."""
+    v = synth.soup(3000, 0.35, 17)
+    c = capi.Context(0, kernel=kernel)
+    c.build_scene_device(capi.make_triangles(v))
+    _check(c, po.OracleScene(v), f"kernel={kernel}")
+    c.close()
+
+
+def test_degenerate_inputs_for_the_radix_tree(built):
+    """Equal Morton keys (coincident triangles, a flat cluster with one outlier) are split by index;
+    the tree stays a valid BVH of bounded depth."""
+    base = synth.soup(1, 0.5, 3)
+    same = np.repeat(base, 300, axis=0)                       # 300 copies of one triangle: all keys equal
+    v = np.concatenate([same, synth.soup(50, 0.2, 4) * 0.001, synth.soup(1, 0.5, 9) + 4.0]).astype(np.float32)
+    ids = np.arange(v.shape[0], dtype=np.uint32)[::-1].copy()  # the winner among exact ties is the LOWEST id
+    c = capi.Context(0)
+    c.build_scene_device(capi.make_triangles(v, ids))
+    _check(c, po.OracleScene(v, ids), "degenerate")
+    assert c.scene_info()["stack_need"] <= 64
+    c.close()
+
+
+def test_device_resident_triangles_and_rebuild(built):
+    """Triangles already in HBM (MRT_BUILD_TRIS_ON_DEVICE); a context is rebuilt in place, and a
+    host-built scene can replace a device-built one and vice versa."""
+    c = capi.Context(0)
+    for seed in (1, 2):
+        v = synth.soup(5000, 0.3, seed)
+        tris = capi.make_triangles(v)
+        d = c.device_alloc(tris.nbytes)
+        c.h2d(d, tris)
+        c.build_scene_device(d, n_tris=tris.shape[0], on_device=True)
+        c.device_free(d)
+        _check(c, po.OracleScene(v), f"device tris seed={seed}")
+        assert c.stats()["last_build_ms"] > 0.0
+    v = synth.soup(2000, 0.4, 9)
+    capi.Scene(v).upload(c)                                    # host-built SAH tree over the same context
+    _check(c, po.OracleScene(v), "host after device")
+    c.build_scene_device(capi.make_triangles(v))
+    _check(c, po.OracleScene(v), "device after host")
+    with pytest.raises(capi.MrtError):
+        c.build_scene_device(np.zeros(0, dtype=T.TRI64))
+    c.close()
+
+
+def test_c2_device_build_matches_host_build_on_the_full_grid(built):
+    """Config C2 (100 k triangles, 1024^2 rays): the device-built and the host-built tree give the
+    same 2^20 hit records, byte for byte."""
+    cfg = synth.CONFIGS["C2"]
+    w, h = cfg["grid"]
+    verts = synth.scene_vertices(cfg)
+    cam = capi.camera_look(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
+    c = capi.Context(0)
+    scene = capi.Scene(verts)
+    scene.upload(c)
+    host = c.cast_grid(cam, w, h)
+    c.build_scene_device(scene.tris)
+    dev = c.cast_grid(cam, w, h)
+    assert dev.tobytes() == host.tobytes()
+    inc = synth.incoherent_rays(1 << 18, 77)
+    got = c.cast(inc)
+    scene.upload(c)
+    assert got.tobytes() == c.cast(inc).tobytes()
+    c.close()

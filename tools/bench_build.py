@@ -1,0 +1,82 @@
+#!/usr/bin/env python3
+"""Build time and trace time: host-built 8-bin SAH tree (mrt_bvh2_build + mrt_upload_scene) against
+the device-built LBVH (mrt_build_scene_device), on one config's scene and primary-ray grid.
+
+    python tools/bench_build.py --config C3 [--rounds 5]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from messyerraytracer_amd import capi, synth, types as T  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="C3")
+    ap.add_argument("--rounds", type=int, default=5)
+    a = ap.parse_args()
+    cfg = synth.CONFIGS[a.config]
+    w, h = cfg["grid"]
+    verts = synth.scene_vertices(cfg)
+    tris = capi.make_triangles(verts)
+    n = tris.shape[0]
+    cam = capi.camera_look(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
+    ctx = capi.Context(0)
+    d_hits = ctx.device_alloc(w * h * 32)
+    out = dict(config=a.config, tris=int(n), rays=w * h)
+
+    def trace_ms():
+        ts = []
+        for _ in range(a.rounds):
+            ctx.cast_grid(cam, w, h, hits=d_hits, flags=capi.FLAG_HITS_ON_DEVICE)
+            ts.append(ctx.stats()["last_trace_ms"])
+        return float(np.median(ts))
+
+    def digest():
+        hits = np.zeros(w * h, dtype=T.HIT32)
+        ctx.d2h(hits, d_hits)
+        return hits
+
+    # host: build (threads = all cores of this process) + conversion + upload
+    t0 = time.perf_counter()
+    verts4 = T.verts4_from_verts9(verts)
+    nodes, prim_idx, used = capi.bvh2_build(verts4, 0)
+    t1 = time.perf_counter()
+    ctx.upload_scene(tris, nodes, prim_idx)
+    t2 = time.perf_counter()
+    out["host"] = dict(build_s=t1 - t0, upload_s=t2 - t1, threads=len(os.sched_getaffinity(0)),
+                       stack_need=ctx.scene_info()["stack_need"], trace_ms=trace_ms())
+    host_hits = digest()
+
+    # device: triangles from host memory (PCIe included in wall time), and already resident
+    walls, devs = [], []
+    for _ in range(a.rounds):
+        t0 = time.perf_counter()
+        ctx.build_scene_device(tris)
+        walls.append(time.perf_counter() - t0)
+        devs.append(ctx.stats()["last_build_ms"])
+    d_tris = ctx.device_alloc(tris.nbytes)
+    ctx.h2d(d_tris, tris)
+    res = []
+    for _ in range(a.rounds):
+        ctx.build_scene_device(d_tris, n_tris=n, on_device=True)
+        res.append(ctx.stats()["last_build_ms"])
+    out["device"] = dict(build_ms_from_host_tris=float(np.median(devs)), wall_ms_from_host_tris=float(np.median(walls)) * 1e3,
+                         build_ms_resident_tris=float(np.median(res)), stack_need=ctx.scene_info()["stack_need"], trace_ms=trace_ms())
+    out["identical_hits"] = bool(digest().tobytes() == host_hits.tobytes())
+    out["mtris_per_s_device_build"] = n / out["device"]["build_ms_resident_tris"] / 1e3
+    print(json.dumps(out), flush=True)
+    ctx.device_free(d_tris)
+    ctx.device_free(d_hits)
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
