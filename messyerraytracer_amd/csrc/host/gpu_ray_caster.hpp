@@ -57,6 +57,16 @@ public:
 				(uint32_t)triangles.size(), packed.data());
 		report(mrt_upload_scene(ctx_, packed.data(), (uint32_t)packed.size(), bvh_nodes, used_nodes, prim_idx), "upload_scene");
 	}
+	// No reference counterpart: build the acceleration structure on the device from the triangles
+	// alone (LBVH, milliseconds) instead of scene.build() + upload_scene(); same hit records.
+	void build_scene_on_device(const std::vector<Triangle> &triangles)
+	{
+		if (!ctx_ || triangles.empty()) return;
+		std::vector<mrt_tri64> packed(triangles.size());
+		mrt_pack_host_triangles(reinterpret_cast<const mrt_host_tri80 *>(triangles.data()),
+				(uint32_t)triangles.size(), packed.data());
+		report(mrt_build_scene_device(ctx_, packed.data(), (uint32_t)packed.size(), 0), "build_scene_on_device");
+	}
 	// CWBVH is a Vulkan-path layout (cpp:351-411); accepted and ignored.
 	void upload_cwbvh(const void * /*cwbvh*/) {}
 

@@ -6,7 +6,7 @@
 // usage: host_mirror_test <in.bin> <out.bin>
 //   in : u32 n_tris, f32 verts[n_tris*9], u32 n_rays, Ray rays[n_rays] (60 B each)
 //   out: i32 header[8], then Intersection[n] coherent, Intersection[n] sorted,
-//        u8[n] any-hit, Intersection[n] async, Intersection single
+//        u8[n] any-hit, Intersection[n] async, Intersection single, Intersection[n] after a device-side rebuild
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -61,6 +61,11 @@ int main(int argc, char **argv)
 	if (!was_pending || disp.has_gpu_pending()) { std::fprintf(stderr, "async bookkeeping broken\n"); return 4; }
 	Intersection single = disp.cast_ray(rays[0]);
 	if (stats.rays_cast != 3ull * n_rays) { std::fprintf(stderr, "stats broken\n"); return 5; }
+	// 4. the same scene rebuilt on the device from the triangles alone: the same records
+	std::vector<Intersection> device_built(n_rays);
+	disp.gpu_caster().build_scene_on_device(disp.scene().triangles);
+	if (!disp.using_gpu()) { std::fprintf(stderr, "device build left no scene\n"); return 6; }
+	disp.cast_rays(rays.data(), device_built.data(), (int)n_rays, nullptr, 0xFFFFFFFF, false);
 
 	FILE *o = std::fopen(argv[2], "wb");
 	if (!o) return 2;
@@ -70,6 +75,7 @@ int main(int argc, char **argv)
 	std::fwrite(any.data(), 1, n_rays, o);
 	std::fwrite((const void *)async_res.data(), sizeof(Intersection), n_rays, o);
 	std::fwrite((const void *)&single, sizeof(Intersection), 1, o);
+	std::fwrite((const void *)device_built.data(), sizeof(Intersection), n_rays, o);
 	std::fclose(o);
 	return 0;
 }

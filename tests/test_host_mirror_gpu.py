@@ -44,7 +44,8 @@ def test_ray_dispatcher_mirror(built, scene):
     sorted_ = np.frombuffer(raw[off:off + 44 * n], dtype=T.HOST_HIT44); off += 44 * n
     any_hit = np.frombuffer(raw[off:off + n], dtype=np.uint8).astype(bool); off += n
     async_ = np.frombuffer(raw[off:off + 44 * n], dtype=T.HOST_HIT44); off += 44 * n
-    single = np.frombuffer(raw[off:off + 44], dtype=T.HOST_HIT44)
+    single = np.frombuffer(raw[off:off + 44], dtype=T.HOST_HIT44); off += 44
+    device_built = np.frombuffer(raw[off:off + 44 * n], dtype=T.HOST_HIT44)
     assert header[0] == 8            # MRT_ERR_UNSUPPORTED for the CPU backend
     assert header[1] == 1 and header[2] == v.shape[0]
     assert header[5] == 0 and header[6] == 0 and header[7] == 0
@@ -56,3 +57,4 @@ def test_ray_dispatcher_mirror(built, scene):
     assert async_.tobytes() == want.tobytes()
     assert np.array_equal(any_hit, want["prim_id"] != 0xFFFFFFFF)
     assert single.tobytes() == want[:1].tobytes()
+    assert device_built.tobytes() == want.tobytes()  # GPURayCaster::build_scene_on_device: same records
