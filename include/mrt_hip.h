@@ -246,6 +246,30 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
  * MRT_ERR_UNSUPPORTED if the tree comes out deeper than the traversal stack (build on the host). */
 enum { MRT_BUILD_TRIS_ON_DEVICE = 1u << 0 };
 int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris, uint32_t flags);
+
+/* A placed mesh: MeshBLAS + BLASInstance (src/accel/mesh_blas.h:86-138, blas_instance.h:47-107).
+ * Several instances may share one mesh (the same first_tri / n_tris). */
+typedef struct mrt_instance {
+	uint32_t first_tri;   /* the mesh: triangles [first_tri, first_tri + n_tris) of the mesh-space array */
+	uint32_t n_tris;
+	uint32_t layers;      /* the mesh's layer mask (raytracer_server.cpp:702-703)                    */
+	uint32_t reserved;
+	float basis[9];       /* Transform3D: world = basis (row-major 3x3) * v + origin                  */
+	float origin[3];
+} mrt_instance;
+
+/* RayTracerServer::_rebuild_scene (src/godot/raytracer_server.cpp:669-711) on the device: every
+ * instance's triangles to world space (Transform3D::xform per vertex, Triangle ctor), ids = running
+ * triangle offset in instance order, layers = the mesh's mask; sum(n_tris) triangles into d_out
+ * (device).  verts9: mesh-space vertices, 9 floats per triangle, host array or device array
+ * (MRT_BUILD_TRIS_ON_DEVICE); instances: host array.  The reference flattens on the host every time
+ * an instance moves and rebuilds; with a 288 GB device, flatten + rebuild per frame (a millisecond
+ * per million triangles + mrt_build_scene_device) is the instancing path here. */
+int mrt_flatten_instances(mrt_ctx *ctx, const float *verts9, uint32_t n_mesh_tris,
+		const mrt_instance *instances, uint32_t n_instances, uint32_t flags, mrt_tri64 *d_out);
+/* mrt_flatten_instances into a scratch buffer + mrt_build_scene_device over it. */
+int mrt_build_instanced_scene_device(mrt_ctx *ctx, const float *verts9, uint32_t n_mesh_tris,
+		const mrt_instance *instances, uint32_t n_instances, uint32_t flags);
 int mrt_is_available(const mrt_ctx *ctx);      /* initialized && scene uploaded */
 int mrt_scene_info(const mrt_ctx *ctx, uint32_t *n_tris, uint32_t *n_wide_nodes, uint32_t *bvh_depth);
 

@@ -27,7 +27,7 @@ KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET, KERNEL_PACKET4, KERNEL_PACKET2, KERNEL_
 SYMBOLS = [
     "mrt_create", "mrt_destroy", "mrt_last_error", "mrt_status_string", "mrt_version", "mrt_set_stream",
     "mrt_synchronize", "mrt_make_triangles", "mrt_pack_host_triangles", "mrt_bvh2_build", "mrt_upload_scene",
-    "mrt_build_scene_device", "mrt_is_available", "mrt_scene_info", "mrt_cast", "mrt_submit", "mrt_collect", "mrt_has_pending",
+    "mrt_build_scene_device", "mrt_flatten_instances", "mrt_build_instanced_scene_device", "mrt_is_available", "mrt_scene_info", "mrt_cast", "mrt_submit", "mrt_collect", "mrt_has_pending",
     "mrt_camera_look", "mrt_generate_grid", "mrt_cast_grid", "mrt_cast_tiled", "mrt_expand_tokens",
     "mrt_expand_grid_tokens", "mrt_morton_keys",
     "mrt_get_stats", "mrt_device_alloc", "mrt_device_free", "mrt_memcpy_h2d", "mrt_memcpy_d2h",
@@ -87,6 +87,8 @@ def load():
     L.mrt_bvh2_build.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
     L.mrt_upload_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
     L.mrt_build_scene_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.mrt_flatten_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
+    L.mrt_build_instanced_scene_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
     L.mrt_is_available.argtypes = [C.c_void_p]
     L.mrt_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.mrt_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32]
@@ -215,6 +217,25 @@ class Context:
             assert tris.dtype == T.TRI64
             n_tris = tris.shape[0]
         self._chk(self.L.mrt_build_scene_device(self.h, _ptr(tris), n_tris, BUILD_TRIS_ON_DEVICE if on_device else 0))
+
+    def flatten_instances(self, verts9, instances, d_out, n_mesh_tris=None, on_device=False):
+        """instances: numpy array of types.INSTANCE; verts9: (n,3,3) float32 mesh-space vertices (or a device pointer)."""
+        if isinstance(verts9, np.ndarray):
+            verts9 = np.ascontiguousarray(verts9, dtype=np.float32)
+            n_mesh_tris = verts9.size // 9
+        instances = np.ascontiguousarray(instances)
+        assert instances.dtype == T.INSTANCE
+        self._chk(self.L.mrt_flatten_instances(self.h, _ptr(verts9), n_mesh_tris, _np(instances), instances.shape[0],
+                                               BUILD_TRIS_ON_DEVICE if on_device else 0, _ptr(d_out)))
+
+    def build_instanced_scene_device(self, verts9, instances, n_mesh_tris=None, on_device=False):
+        if isinstance(verts9, np.ndarray):
+            verts9 = np.ascontiguousarray(verts9, dtype=np.float32)
+            n_mesh_tris = verts9.size // 9
+        instances = np.ascontiguousarray(instances)
+        assert instances.dtype == T.INSTANCE
+        self._chk(self.L.mrt_build_instanced_scene_device(self.h, _ptr(verts9), n_mesh_tris, _np(instances), instances.shape[0],
+                                                          BUILD_TRIS_ON_DEVICE if on_device else 0))
 
     def upload_scene(self, tris, nodes, prim_idx):
         tris = np.ascontiguousarray(tris)

@@ -12,6 +12,7 @@
 #include <cstring>
 #include <string.h>
 #include <new>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 #include "mrt_internal.h"
@@ -20,6 +21,8 @@ namespace mrt {
 hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream);
 hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t stream);
 hipError_t launch_expand_tokens(const TraceParams &p, const uint32_t *tokens, hipStream_t stream);
+hipError_t launch_flatten_instances(const float *d_verts9, const mrt_instance *d_instances, const uint32_t *d_first_out,
+		uint32_t n_instances, uint32_t max_tris_per_instance, mrt_tri64 *d_out, void *stream);
 hipError_t launch_morton_keys(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t *keys, uint32_t *index, hipStream_t stream);
 hipError_t launch_trace_persistent(const TraceParams &p, unsigned long long *next_ray, uint32_t *overflow,
 		uint32_t lds_depth, uint32_t refill, uint32_t leaf_wait, uint32_t blocks, bool any_hit, hipStream_t stream);
@@ -476,6 +479,71 @@ int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	ctx->stats.last_build_ms = ms;
 	ctx->scene = true;
 	return MRT_OK;
+}
+
+// validates the instances, uploads what is on the host, flattens into d_out (device); *total = sum(n_tris)
+static int flatten_instances(mrt_ctx *ctx, const float *verts9, uint32_t n_mesh_tris, const mrt_instance *instances,
+		uint32_t n_instances, uint32_t flags, mrt_tri64 *d_out_or_null, mrt_tri64 **d_out_alloc, uint32_t *total)
+{
+	if (!verts9 || !instances || n_instances == 0) return fail(ctx, MRT_ERR_INVALID, "flatten_instances: no instances");
+	if (n_instances > 65535u) return fail(ctx, MRT_ERR_UNSUPPORTED, "flatten_instances: at most 65535 instances per call");
+	std::vector<uint32_t> first(n_instances);
+	uint64_t sum = 0; uint32_t max_tris = 0;
+	for (uint32_t i = 0; i < n_instances; i++) {
+		const mrt_instance &in = instances[i];
+		if ((uint64_t)in.first_tri + in.n_tris > n_mesh_tris) return fail(ctx, MRT_ERR_INVALID, "flatten_instances: instance outside the mesh array");
+		first[i] = (uint32_t)sum; sum += in.n_tris;
+		if (in.n_tris > max_tris) max_tris = in.n_tris;
+	}
+	if (sum == 0 || sum > 0x7FFFFFFFull) return fail(ctx, MRT_ERR_INVALID, "flatten_instances: triangle count out of range");
+	*total = (uint32_t)sum;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	void *d_inst = nullptr, *d_first = nullptr, *d_verts = nullptr, *d_out = d_out_or_null;
+	auto drop = [&] {
+		if (d_inst) (void)hipFree(d_inst);
+		if (d_first) (void)hipFree(d_first);
+		if (d_verts) (void)hipFree(d_verts);
+	};
+	const bool on_device = (flags & MRT_BUILD_TRIS_ON_DEVICE) != 0;
+	hipError_t e = hipMalloc(&d_inst, (size_t)n_instances * sizeof(mrt_instance));
+	if (e == hipSuccess) e = hipMalloc(&d_first, (size_t)n_instances * 4);
+	if (e == hipSuccess && !on_device) e = hipMalloc(&d_verts, (size_t)n_mesh_tris * 36);
+	if (e == hipSuccess && !d_out) { e = hipMalloc(&d_out, (size_t)sum * sizeof(mrt_tri64)); if (e == hipSuccess) *d_out_alloc = (mrt_tri64 *)d_out; }
+	if (e != hipSuccess) { drop(); return fail(ctx, MRT_ERR_OOM, "flatten_instances: out of device memory"); }
+	e = hipMemcpyAsync(d_inst, instances, (size_t)n_instances * sizeof(mrt_instance), hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = hipMemcpyAsync(d_first, first.data(), (size_t)n_instances * 4, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess && !on_device) e = hipMemcpyAsync(d_verts, verts9, (size_t)n_mesh_tris * 36, hipMemcpyHostToDevice, ctx->stream);
+	if (e == hipSuccess) e = mrt::launch_flatten_instances(on_device ? verts9 : (const float *)d_verts, (const mrt_instance *)d_inst,
+			(const uint32_t *)d_first, n_instances, max_tris, (mrt_tri64 *)d_out, (void *)ctx->stream);
+	if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream); // `first` and the staging buffers go out of scope
+	drop();
+	if (e != hipSuccess) {
+		if (*d_out_alloc) { (void)hipFree(*d_out_alloc); *d_out_alloc = nullptr; }
+		std::snprintf(ctx->err, sizeof(ctx->err), "flatten_instances failed: %s", hipGetErrorString(e));
+		return MRT_ERR_HIP;
+	}
+	return MRT_OK;
+}
+
+int mrt_flatten_instances(mrt_ctx *ctx, const float *verts9, uint32_t n_mesh_tris, const mrt_instance *instances,
+		uint32_t n_instances, uint32_t flags, mrt_tri64 *d_out)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	if (!d_out) return fail(ctx, MRT_ERR_INVALID, "flatten_instances: null output");
+	mrt_tri64 *unused = nullptr; uint32_t total = 0;
+	return flatten_instances(ctx, verts9, n_mesh_tris, instances, n_instances, flags, d_out, &unused, &total);
+}
+
+int mrt_build_instanced_scene_device(mrt_ctx *ctx, const float *verts9, uint32_t n_mesh_tris, const mrt_instance *instances,
+		uint32_t n_instances, uint32_t flags)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	mrt_tri64 *d_world = nullptr; uint32_t total = 0;
+	int rc = flatten_instances(ctx, verts9, n_mesh_tris, instances, n_instances, flags, nullptr, &d_world, &total);
+	if (rc) return rc;
+	rc = mrt_build_scene_device(ctx, d_world, total, MRT_BUILD_TRIS_ON_DEVICE);
+	(void)hipFree(d_world);
+	return rc;
 }
 
 int mrt_is_available(const mrt_ctx *ctx) { return ctx && ctx->scene ? 1 : 0; }

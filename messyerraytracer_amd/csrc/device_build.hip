@@ -46,28 +46,37 @@ __device__ __forceinline__ float ulp_up(float f) { return f == 0.0f ? FLT_MIN : 
 
 // 1. box of every triangle (vertices v0, v0+e1, v0+e2 as the intersection test sees them) and the
 //    bounds of all boxes: bounds[0..2] = min (ordered uint), bounds[3..5] = max.
+//    Grid-stride over at most LBVH_BOUNDS_BLOCKS blocks, one atomic per block and component: atomics on
+//    one address cost ~10 ns each chip-wide (one per wave made this kernel 1 ms per million triangles).
+#define LBVH_BOUNDS_BLOCKS 1024u
 __global__ __launch_bounds__(LBVH_WG) void lbvh_bounds_kernel(const mrt_tri64 *tris, uint32_t n, Box *boxes, uint32_t *bounds)
 {
-	const uint32_t i = blockIdx.x * LBVH_WG + threadIdx.x;
+	__shared__ float part[LBVH_WG / 64][6];
 	float mn[3] = { FLT_MAX, FLT_MAX, FLT_MAX }, mx[3] = { -FLT_MAX, -FLT_MAX, -FLT_MAX };
-	if (i < n) {
+	for (uint32_t i = blockIdx.x * LBVH_WG + threadIdx.x; i < n; i += gridDim.x * LBVH_WG) {
 		const float4 *t = reinterpret_cast<const float4 *>(tris + i);
 		const float4 a = t[0], b = t[1], c = t[2];
 		const float v0[3] = { a.x, a.y, a.z }, e1[3] = { b.x, b.y, b.z }, e2[3] = { c.x, c.y, c.z };
 		Box bx;
 		for (int k = 0; k < 3; k++) {
 			const float p1 = v0[k] + e1[k], p2 = v0[k] + e2[k];
-			mn[k] = ulp_down(fminf(v0[k], fminf(p1, p2)));
-			mx[k] = ulp_up(fmaxf(v0[k], fmaxf(p1, p2)));
-			bx.mn[k] = mn[k]; bx.mx[k] = mx[k];
+			bx.mn[k] = ulp_down(fminf(v0[k], fminf(p1, p2)));
+			bx.mx[k] = ulp_up(fmaxf(v0[k], fmaxf(p1, p2)));
+			mn[k] = fminf(mn[k], bx.mn[k]); mx[k] = fmaxf(mx[k], bx.mx[k]);
 		}
 		boxes[i] = bx;
 	}
-	// wave reduction, one atomic per wave and component
 	for (int k = 0; k < 3; k++) {
 		float lo = mn[k], hi = mx[k];
 		for (int off = 32; off > 0; off >>= 1) { lo = fminf(lo, __shfl_xor(lo, off)); hi = fmaxf(hi, __shfl_xor(hi, off)); }
-		if ((threadIdx.x & 63u) == 0u) { atomicMin(&bounds[k], f2ord(lo)); atomicMax(&bounds[3 + k], f2ord(hi)); }
+		if ((threadIdx.x & 63u) == 0u) { part[threadIdx.x >> 6][k] = lo; part[threadIdx.x >> 6][3 + k] = hi; }
+	}
+	__syncthreads();
+	if (threadIdx.x < 6u) {
+		const bool is_min = threadIdx.x < 3u;
+		float v = part[0][threadIdx.x];
+		for (uint32_t w = 1; w < LBVH_WG / 64; w++) v = is_min ? fminf(v, part[w][threadIdx.x]) : fmaxf(v, part[w][threadIdx.x]);
+		if (is_min) atomicMin(&bounds[threadIdx.x], f2ord(v)); else atomicMax(&bounds[threadIdx.x], f2ord(v));
 	}
 }
 
@@ -146,7 +155,35 @@ __global__ __launch_bounds__(LBVH_WG) void lbvh_hierarchy_kernel(const uint64_t 
 // 5. One thread per leaf climbs towards the root.  The first thread to reach a node leaves (its
 //    sibling subtree is not finished); the second owns the node: both child boxes are final, it
 //    writes the DevNode row and the node's own box and climbs on.  The hand-off between the two
-//    threads (any two CUs, any two XCDs) is the agent-scope acquire-release counter.
+//    threads (any two CUs, any two XCDs; per-XCD L2s and per-CU L1s are not coherent) follows the
+//    write-through form of the guide's inter-workgroup recipe: the handed-off words (a node's box
+//    and depth) are stored and loaded ONLY by agent-scope relaxed atomics (sc1: they bypass the
+//    non-coherent caches), the storing thread drains them (s_waitcnt vmcnt(0)) before it adds to
+//    the parent's arrival counter, itself an agent-scope atomic.  (An acquire-release counter
+//    with plain loads and stores is also correct and measured 3x slower here: every one of the
+//    two million atomics then writes back and invalidates caches.)
+typedef __attribute__((address_space(1))) unsigned long long lbvh_gu64;
+typedef __attribute__((address_space(1))) unsigned int lbvh_gu32;
+#define LBVH_RLX __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT
+
+__device__ __forceinline__ Box load_box_coherent(const Box *src)
+{
+	lbvh_gu64 *p = (lbvh_gu64 *)src;
+	const unsigned long long a = __hip_atomic_load(p, LBVH_RLX), b = __hip_atomic_load(p + 1, LBVH_RLX), c = __hip_atomic_load(p + 2, LBVH_RLX);
+	Box r;
+	r.mn[0] = __uint_as_float((uint32_t)a); r.mn[1] = __uint_as_float((uint32_t)(a >> 32));
+	r.mn[2] = __uint_as_float((uint32_t)b); r.mx[0] = __uint_as_float((uint32_t)(b >> 32));
+	r.mx[1] = __uint_as_float((uint32_t)c); r.mx[2] = __uint_as_float((uint32_t)(c >> 32));
+	return r;
+}
+__device__ __forceinline__ void store_box_coherent(Box *dst, const Box &b)
+{
+	lbvh_gu64 *p = (lbvh_gu64 *)dst;
+	__hip_atomic_store(p, (unsigned long long)__float_as_uint(b.mn[0]) | ((unsigned long long)__float_as_uint(b.mn[1]) << 32), LBVH_RLX);
+	__hip_atomic_store(p + 1, (unsigned long long)__float_as_uint(b.mn[2]) | ((unsigned long long)__float_as_uint(b.mx[0]) << 32), LBVH_RLX);
+	__hip_atomic_store(p + 2, (unsigned long long)__float_as_uint(b.mx[1]) | ((unsigned long long)__float_as_uint(b.mx[2]) << 32), LBVH_RLX);
+}
+
 __global__ __launch_bounds__(LBVH_WG) void lbvh_fit_kernel(uint32_t n, const Box *tri_boxes, const uint32_t *sorted_tri,
 		const uint32_t *left, const uint32_t *right, const uint32_t *parent_of_node, const uint32_t *parent_of_leaf,
 		uint32_t *arrivals, Box *node_box, uint32_t *node_depth, DevNode *nodes, uint32_t *max_depth)
@@ -155,12 +192,13 @@ __global__ __launch_bounds__(LBVH_WG) void lbvh_fit_kernel(uint32_t n, const Box
 	if (leaf >= n) return;
 	uint32_t node = parent_of_leaf[leaf];
 	for (;;) {
-		const uint32_t before = __hip_atomic_fetch_add(&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+		const uint32_t before = __hip_atomic_fetch_add((lbvh_gu32 *)&arrivals[node], 1u, LBVH_RLX);
 		if (before == 0u) return;
 		const uint32_t l = left[node], r = right[node];
-		const Box lb = (l & kLeafBit) ? tri_boxes[sorted_tri[l & 0x7FFFFFFFu]] : node_box[l];
-		const Box rb = (r & kLeafBit) ? tri_boxes[sorted_tri[r & 0x7FFFFFFFu]] : node_box[r];
-		const uint32_t dl = (l & kLeafBit) ? 0u : node_depth[l], dr = (r & kLeafBit) ? 0u : node_depth[r];
+		const Box lb = (l & kLeafBit) ? tri_boxes[sorted_tri[l & 0x7FFFFFFFu]] : load_box_coherent(&node_box[l]);
+		const Box rb = (r & kLeafBit) ? tri_boxes[sorted_tri[r & 0x7FFFFFFFu]] : load_box_coherent(&node_box[r]);
+		const uint32_t dl = (l & kLeafBit) ? 0u : __hip_atomic_load((lbvh_gu32 *)&node_depth[l], LBVH_RLX);
+		const uint32_t dr = (r & kLeafBit) ? 0u : __hip_atomic_load((lbvh_gu32 *)&node_depth[r], LBVH_RLX);
 		DevNode g;
 		Box u;
 		for (int k = 0; k < 3; k++) {
@@ -170,10 +208,11 @@ __global__ __launch_bounds__(LBVH_WG) void lbvh_fit_kernel(uint32_t n, const Box
 		g.left_ref = l; g.right_ref = r;
 		g.left_count = (l & kLeafBit) ? 1u : 0u; g.right_count = (r & kLeafBit) ? 1u : 0u;
 		nodes[node] = g;
-		node_box[node] = u;
 		const uint32_t depth = (dl > dr ? dl : dr) + 1u;
-		node_depth[node] = depth;
 		if (node == 0u) { *max_depth = depth; return; }
+		store_box_coherent(&node_box[node], u);
+		__hip_atomic_store((lbvh_gu32 *)&node_depth[node], depth, LBVH_RLX);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the box and depth are out before the parent's counter moves
 		node = parent_of_node[node];
 	}
 }
@@ -193,9 +232,54 @@ __global__ __launch_bounds__(LBVH_WG) void lbvh_leaves_kernel(const mrt_tri64 *t
 	reinterpret_cast<float4 *>(cold)[slot] = nn;
 }
 
+// Instances -> world-space triangles: the loop of RayTracerServer::_rebuild_scene
+// (src/godot/raytracer_server.cpp:700-711).  Per vertex Transform3D::xform = basis row . v + origin
+// (dot product summed left to right), then the Triangle ctor (src/core/triangle.h:41-51, the
+// arithmetic of mrt_make_triangles), id = running triangle offset in instance order, layers = the
+// mesh's layer mask.  blockIdx.y = instance.
+__global__ __launch_bounds__(LBVH_WG) void flatten_instances_kernel(const float *verts9, const mrt_instance *instances,
+		const uint32_t *first_out, mrt_tri64 *out)
+{
+	const mrt_instance in = instances[blockIdx.y];
+	const uint32_t k = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (k >= in.n_tris) return;
+	const float *src = verts9 + 9u * (size_t)(in.first_tri + k);
+	float w[3][3];
+	for (int v = 0; v < 3; v++) {
+		const float x = src[3 * v], y = src[3 * v + 1], z = src[3 * v + 2];
+		for (int r = 0; r < 3; r++)
+			w[v][r] = ((in.basis[3 * r] * x + in.basis[3 * r + 1] * y) + in.basis[3 * r + 2] * z) + in.origin[r];
+	}
+	float e1[3], e2[3], n[3];
+	for (int c = 0; c < 3; c++) { e1[c] = w[1][c] - w[0][c]; e2[c] = w[2][c] - w[0][c]; }
+	n[0] = e1[1] * e2[2] - e1[2] * e2[1];
+	n[1] = e1[2] * e2[0] - e1[0] * e2[2];
+	n[2] = e1[0] * e2[1] - e1[1] * e2[0];
+	const float l2 = n[0] * n[0] + n[1] * n[1] + n[2] * n[2];
+	if (l2 == 0.0f) { n[0] = n[1] = n[2] = 0.0f; }
+	else { const float l = __builtin_sqrtf(l2); n[0] /= l; n[1] /= l; n[2] /= l; }
+	const uint32_t id = first_out[blockIdx.y] + k;
+	float4 *dst = reinterpret_cast<float4 *>(out + id);
+	float4 a, b, c, d;
+	a.x = w[0][0]; a.y = w[0][1]; a.z = w[0][2]; a.w = __uint_as_float(id);
+	b.x = e1[0]; b.y = e1[1]; b.z = e1[2]; b.w = __uint_as_float(in.layers);
+	c.x = e2[0]; c.y = e2[1]; c.z = e2[2]; c.w = 0.0f;
+	d.x = n[0]; d.y = n[1]; d.z = n[2]; d.w = 0.0f;
+	dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
+}
+
 } // namespace
 
-#define DB_TRY(call)                                                                                     \
+hipError_t launch_flatten_instances(const float *d_verts9, const mrt_instance *d_instances, const uint32_t *d_first_out,
+		uint32_t n_instances, uint32_t max_tris_per_instance, mrt_tri64 *d_out, void *stream)
+{
+	if (n_instances == 0 || max_tris_per_instance == 0) return hipSuccess;
+	hipLaunchKernelGGL(flatten_instances_kernel, dim3((max_tris_per_instance + LBVH_WG - 1) / LBVH_WG, n_instances), dim3(LBVH_WG), 0,
+			(hipStream_t)stream, d_verts9, d_instances, d_first_out, d_out);
+	return hipGetLastError();
+}
+
+#define DB_TRY(call)                                                                                    \
 	do {                                                                                                 \
 		hipError_t e_ = (call);                                                                          \
 		if (e_ != hipSuccess) {                                                                          \
@@ -242,7 +326,8 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, void *stream_, Device
 	const uint32_t init[8] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u };
 	DB_TRY(hipMemcpyAsync(scal, init, sizeof(init), hipMemcpyHostToDevice, stream));
 	DB_TRY(hipMemsetAsync(arrivals, 0, nn * 4, stream));
-	hipLaunchKernelGGL(lbvh_bounds_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, d_tris, n, boxes, scal);
+	hipLaunchKernelGGL(lbvh_bounds_kernel, dim3(blocks < LBVH_BOUNDS_BLOCKS ? blocks : LBVH_BOUNDS_BLOCKS), dim3(LBVH_WG), 0, stream,
+			d_tris, n, boxes, scal);
 	hipLaunchKernelGGL(lbvh_keys_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, boxes, n, scal, keys_a, idx_a);
 	size_t sort_bytes = 0;
 	DB_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_a, keys_b, idx_a, idx_b, nn, 0, 63, stream));

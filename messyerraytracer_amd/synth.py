@@ -148,6 +148,46 @@ def multi_mesh(n_meshes: int = 64, tris_per_mesh: int = 156250, s: float = 0.025
     return verts, mesh_id
 
 
+def multi_mesh_instances(n_meshes: int = 64, tris_per_mesh: int = 156250, s: float = 0.025, seed: int = 100):
+    """The same scene as multi_mesh() before flattening: mesh-space vertices (n_meshes*tris_per_mesh,3,3)
+    and one types.INSTANCE per mesh (rotation + lattice-cell origin), the input of
+    mrt_build_instanced_scene_device.  flatten_instances(*multi_mesh_instances(...)) == multi_mesh(...)[0]."""
+    from . import types as T
+    side = 4
+    cell = np.float32(10.0 / side)
+    scale = np.float32(0.24)
+    local = np.empty((n_meshes * tris_per_mesh, 3, 3), dtype=np.float32)
+    inst = np.zeros(n_meshes, dtype=T.INSTANCE)
+    quats = _unit_vectors(seed + 0xA11CE, n_meshes, 4)
+    for m in range(n_meshes):
+        local[m * tris_per_mesh:(m + 1) * tris_per_mesh] = soup(tris_per_mesh, s, seed + m) * scale
+        w, x, y, z = [np.float32(v) for v in quats[m]]
+        two, one = np.float32(2.0), np.float32(1.0)
+        rot = np.array([[one - two * (y * y + z * z), two * (x * y - w * z), two * (x * z + w * y)],
+                        [two * (x * y + w * z), one - two * (x * x + z * z), two * (y * z - w * x)],
+                        [two * (x * z - w * y), two * (y * z + w * x), one - two * (x * x + y * y)]], dtype=np.float32)
+        lattice = m % (side ** 3)
+        inst[m]["first_tri"], inst[m]["n_tris"], inst[m]["layers"] = m * tris_per_mesh, tris_per_mesh, 0xFFFFFFFF
+        inst[m]["basis"] = rot.reshape(9)
+        inst[m]["origin"] = [np.float32(-5.0) + cell * np.float32((lattice % side) + 0.5),
+                             np.float32(-5.0) + cell * np.float32(((lattice // side) % side) + 0.5),
+                             np.float32(-5.0) + cell * np.float32((lattice // (side * side)) + 0.5)]
+    return local, inst
+
+
+def flatten_instances(local: np.ndarray, inst: np.ndarray) -> np.ndarray:
+    """World-space vertices of every instance, in instance order: Transform3D::xform per vertex as
+    RayTracerServer::_rebuild_scene applies it (raytracer_server.cpp:700-711): basis row . v summed
+    left to right, plus origin, all in float32."""
+    out = []
+    for i in inst:
+        p = local[int(i["first_tri"]):int(i["first_tri"]) + int(i["n_tris"])].reshape(-1, 3)
+        b, o = i["basis"].astype(np.float32), i["origin"].astype(np.float32)
+        w = [p[:, 0] * b[3 * r] + p[:, 1] * b[3 * r + 1] + p[:, 2] * b[3 * r + 2] + o[r] for r in range(3)]
+        out.append(np.stack(w, axis=1).reshape(-1, 3, 3))
+    return np.concatenate(out).astype(np.float32)
+
+
 # Named workloads of BASELINE.json `configs`.
 CONFIGS = {
     "C1": dict(scene="cube", grid=(16, 12), origin=(0.0, 0.0, 3.0), forward=(0.0, 0.0, -1.0), fov=60.0),

@@ -22,6 +22,10 @@ HOST_HIT44 = np.dtype([("t", "<f4"), ("position", "<f4", 3), ("normal", "<f4", 3
 HOST_TRI80 = np.dtype([("v0", "<f4", 3), ("v1", "<f4", 3), ("v2", "<f4", 3), ("edge1", "<f4", 3),
                        ("edge2", "<f4", 3), ("normal", "<f4", 3), ("id", "<u4"), ("layers", "<u4")])
 
+INSTANCE = np.dtype([("first_tri", "<u4"), ("n_tris", "<u4"), ("layers", "<u4"), ("reserved", "<u4"),
+                     ("basis", "<f4", 9), ("origin", "<f4", 3)])  # mrt_instance
+
+assert INSTANCE.itemsize == 64
 assert RAY32.itemsize == 32 and HIT32.itemsize == 32 and TRI64.itemsize == 64
 assert NODE32.itemsize == 32 and WIDE64.itemsize == 64
 assert HOST_RAY60.itemsize == 60 and HOST_HIT44.itemsize == 44 and HOST_TRI80.itemsize == 80

@@ -113,3 +113,12 @@ def test_product_does_not_reference_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+def test_instances_flatten_to_the_multi_mesh_scene():
+    """synth.multi_mesh_instances + synth.flatten_instances (the host statement of
+    raytracer_server.cpp:700-711) reproduce the C5 generator bit for bit."""
+    from messyerraytracer_amd import synth
+    local, inst = synth.multi_mesh_instances(5, 300, 0.05, 11)
+    assert synth.flatten_instances(local, inst).tobytes() == synth.multi_mesh(5, 300, 0.05, 11)[0].tobytes()
+    assert inst["n_tris"].sum() == 1500 and inst.dtype.itemsize == 64

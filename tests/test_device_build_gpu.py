@@ -113,3 +113,43 @@ def test_c2_device_build_matches_host_build_on_the_full_grid(built):
     scene.upload(c)
     assert got.tobytes() == c.cast(inc).tobytes()
     c.close()
+
+
+def test_instances_flattened_and_built_on_the_device(built):
+    """mrt_flatten_instances == the host flatten of RayTracerServer::_rebuild_scene + the Triangle
+    ctor, bit for bit (meshes shared by several instances, per-mesh layer masks, running ids), and
+    mrt_build_instanced_scene_device gives the oracle's hits on the flattened scene."""
+    local, inst = synth.multi_mesh_instances(8, 2000, 0.1, 7)
+    extra = inst[[0, 3]].copy()                       # true instancing: meshes 0 and 3 placed a second time
+    extra["origin"] += np.array([0.5, -0.25, 1.0], dtype=np.float32)
+    extra["layers"] = [0x2, 0x4]
+    inst = np.concatenate([inst, extra])
+    world = synth.flatten_instances(local, inst)
+    n = world.shape[0]
+    assert n == 10 * 2000
+    ids = np.arange(n, dtype=np.uint32)
+    layers = np.repeat(inst["layers"], inst["n_tris"]).astype(np.uint32)
+    want = capi.make_triangles(world, ids, layers)
+    c = capi.Context(0)
+    d_out = c.device_alloc(n * 64)
+    c.flatten_instances(local, inst, d_out)
+    got = np.zeros(n, dtype=T.TRI64)
+    c.d2h(got, d_out)
+    assert got.tobytes() == want.tobytes()
+    # mesh vertices already on the device
+    d_local = c.device_alloc(local.nbytes)
+    c.h2d(d_local, local)
+    c.flatten_instances(d_local, inst, d_out, n_mesh_tris=local.shape[0], on_device=True)
+    c.d2h(got, d_out)
+    assert got.tobytes() == want.tobytes()
+    osc = po.OracleScene(world, ids, layers)
+    c.build_instanced_scene_device(local, inst)
+    _check(c, osc, "instanced", masks=(0xFFFFFFFF, 0x2))
+    c.build_instanced_scene_device(d_local, inst, n_mesh_tris=local.shape[0], on_device=True)
+    _check(c, osc, "instanced, resident meshes")
+    bad = inst.copy()
+    bad["n_tris"][1] = local.shape[0]                 # runs past the mesh array
+    with pytest.raises(capi.MrtError):
+        c.build_instanced_scene_device(local, bad)
+    c.device_free(d_out); c.device_free(d_local)
+    c.close()

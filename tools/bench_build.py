@@ -71,6 +71,20 @@ def main():
     out["device"] = dict(build_ms_from_host_tris=float(np.median(devs)), wall_ms_from_host_tris=float(np.median(walls)) * 1e3,
                          build_ms_resident_tris=float(np.median(res)), stack_need=ctx.scene_info()["stack_need"], trace_ms=trace_ms())
     out["identical_hits"] = bool(digest().tobytes() == host_hits.tobytes())
+    if cfg.get("scene") == "multi_mesh":
+        # the same scene as placed meshes: flatten (Transform3D::xform + Triangle ctor) and build on the device
+        local, inst = synth.multi_mesh_instances(cfg["n_meshes"], cfg["tris_per_mesh"], cfg["s"], cfg["seed"])
+        d_local = ctx.device_alloc(local.nbytes)
+        ctx.h2d(d_local, local)
+        ws = []
+        for _ in range(a.rounds):
+            t0 = time.perf_counter()
+            ctx.build_instanced_scene_device(d_local, inst, n_mesh_tris=local.shape[0], on_device=True)
+            ws.append(time.perf_counter() - t0)
+        ctx.cast_grid(cam, w, h, hits=d_hits, flags=capi.FLAG_HITS_ON_DEVICE)
+        out["instanced"] = dict(instances=int(inst.shape[0]), flatten_plus_build_wall_ms=float(np.median(ws)) * 1e3,
+                                build_ms=ctx.stats()["last_build_ms"], identical_hits=bool(digest().tobytes() == host_hits.tobytes()))
+        ctx.device_free(d_local)
     out["mtris_per_s_device_build"] = n / out["device"]["build_ms_resident_tris"] / 1e3
     print(json.dumps(out), flush=True)
     ctx.device_free(d_tris)
