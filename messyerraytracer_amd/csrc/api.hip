@@ -135,7 +135,8 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 // primary-ray grids), one lane per ray for everything else (sorted / incoherent batches).
 uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent)
 {
-	if (ctx->opts.kernel == MRT_KERNEL_PACKET4 && !ctx->d_nodes4) return MRT_KERNEL_PACKET; // device-built scenes have no 4-wide layout
+	// the 4-wide packet kernel keeps 128 stack entries per wave; a device-built tree only has a loose bound
+	if (ctx->opts.kernel == MRT_KERNEL_PACKET4 && (!ctx->d_nodes4 || ctx->stack4 > 128u)) return MRT_KERNEL_PACKET;
 	if (ctx->opts.kernel >= MRT_KERNEL_LANE && ctx->opts.kernel <= MRT_KERNEL_LANE4_PERSISTENT) return ctx->opts.kernel;
 	// (PACKET4 halves the fetch chain but measured 7 % slower at C3: the walk is bound by
 	// instruction issue, and ordering four children costs more scalar work than it saves)
@@ -458,11 +459,14 @@ int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 		d_tris = (const mrt_tri64 *)staged;
 	}
 	mrt::DeviceBuildResult b;
-	rc = mrt::device_build_lbvh(d_tris, n_tris, (void *)ctx->stream, &b, ctx->err, sizeof(ctx->err));
+	const bool want4 = ctx->opts.kernel == MRT_KERNEL_PACKET4 || ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
+			ctx->opts.kernel == MRT_KERNEL_AUTO;
+	rc = mrt::device_build_lbvh(d_tris, n_tris, want4, (void *)ctx->stream, &b, ctx->err, sizeof(ctx->err));
 	if (staged) (void)hipFree(staged);
 	if (rc) return rc;
 	if (b.depth > 64) { // the packet kernels keep 64 stack entries per wave
 		(void)hipFree(b.nodes); (void)hipFree(b.hot); (void)hipFree(b.cold);
+		if (b.nodes4) (void)hipFree(b.nodes4);
 		return fail(ctx, MRT_ERR_UNSUPPORTED, "device-built BVH deeper than the 64-entry traversal stack: build on the host");
 	}
 	HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
@@ -471,7 +475,7 @@ int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
 	free_scene(ctx);
 	ctx->d_nodes = b.nodes; ctx->d_hot = b.hot; ctx->d_cold = b.cold;
-	ctx->d_nodes4 = nullptr; ctx->n_nodes4 = 0; ctx->stack4 = 0; // no 4-wide collapse of a device-built tree (yet)
+	ctx->d_nodes4 = b.nodes4; ctx->n_nodes4 = b.nodes4 ? b.n_nodes : 0; ctx->stack4 = b.stack4;
 	ctx->n_nodes = b.n_nodes; ctx->n_tris = b.n_tris; ctx->depth = b.depth;
 	for (int c = 0; c < 3; c++) { ctx->bounds_lo[c] = b.bounds_lo[c]; ctx->bounds_hi[c] = b.bounds_hi[c]; }
 	ctx->stack_depth = ((b.depth + 7u) / 8u) * 8u;

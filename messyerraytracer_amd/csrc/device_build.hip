@@ -217,6 +217,45 @@ __global__ __launch_bounds__(LBVH_WG) void lbvh_fit_kernel(uint32_t n, const Box
 	}
 }
 
+// 5b. 4-wide collapse for the incoherent-ray kernel (one 128-byte line per step): the rule of
+//     scene_prep.cpp (start from a node's two children, keep opening the internal child with the
+//     largest half-area until there are four).  Every binary node gets the 4-wide node it WOULD be
+//     the root of, at its own index, so no allocation or top-down pass is needed; only the ones
+//     reachable from node 0 are ever read (the others cost HBM capacity, not bandwidth).
+__global__ __launch_bounds__(LBVH_WG) void lbvh_collapse4_kernel(const DevNode *nodes, uint32_t n_nodes, Dev4Node *nodes4)
+{
+	const uint32_t b = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (b >= n_nodes) return;
+	float box[4][6]; uint32_t ref[4]; uint32_t n = 2;
+	auto take = [&](const DevNode &g, uint32_t at_l, uint32_t at_r) {
+		for (int k = 0; k < 3; k++) {
+			box[at_l][k] = g.lmin[k]; box[at_l][3 + k] = g.lmax[k];
+			box[at_r][k] = g.rmin[k]; box[at_r][3 + k] = g.rmax[k];
+		}
+		ref[at_l] = g.left_ref; ref[at_r] = g.right_ref;
+	};
+	take(nodes[b], 0, 1);
+	while (n < 4) {
+		int best = -1; float best_a = -1.0f;
+		for (uint32_t i = 0; i < n; i++) {
+			if (ref[i] >= kSentinel) continue; // a leaf
+			const float e0 = box[i][3] - box[i][0], e1 = box[i][4] - box[i][1], e2 = box[i][5] - box[i][2];
+			const float a = e0 * e1 + e1 * e2 + e2 * e0;
+			if (a > best_a) { best_a = a; best = (int)i; }
+		}
+		if (best < 0) break;
+		take(nodes[ref[best]], (uint32_t)best, n);
+		n++;
+	}
+	Dev4Node out;
+	for (uint32_t i = 0; i < 4; i++) {
+		for (int k = 0; k < 6; k++) out.box[i][k] = i < n ? box[i][k] : __builtin_inff(); // unused slot: never hit
+		out.ref[i] = i < n ? ref[i] : kSentinel;
+	}
+	out.n_children = n; out.pad[0] = out.pad[1] = out.pad[2] = 0u;
+	nodes4[b] = out;
+}
+
 // 6. triangle rows in leaf order (sorted position = slot); every leaf holds one triangle
 __global__ __launch_bounds__(LBVH_WG) void lbvh_leaves_kernel(const mrt_tri64 *tris, uint32_t n, const uint32_t *sorted_tri, TriHot *hot, TriCold *cold)
 {
@@ -289,16 +328,17 @@ hipError_t launch_flatten_instances(const float *d_verts9, const mrt_instance *d
 		}                                                                                                \
 	} while (0)
 
-// Builds nodes / hot / cold (hipMalloc'ed, owned by the caller on success) for the n >= 2 triangles
-// at d_tris (device).  depth = stack entries a traversal can need (incl. the sentinel).
-int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, void *stream_, DeviceBuildResult *out, char *err, size_t err_len)
+// Builds nodes / hot / cold (and nodes4 if want4; hipMalloc'ed, owned by the caller on success) for the
+// n >= 2 triangles at d_tris (device).  depth = stack entries a traversal can need (incl. the sentinel).
+int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, void *stream_, DeviceBuildResult *out, char *err, size_t err_len)
 {
 	hipStream_t stream = (hipStream_t)stream_;
 	void *tmp[16] = {}; int n_tmp = 0;
-	DevNode *nodes = nullptr; TriHot *hot = nullptr; TriCold *cold = nullptr;
+	DevNode *nodes = nullptr; TriHot *hot = nullptr; TriCold *cold = nullptr; Dev4Node *nodes4 = nullptr;
 	auto cleanup = [&] {
 		for (int i = 0; i < n_tmp; i++) if (tmp[i]) (void)hipFree(tmp[i]);
 		if (nodes) (void)hipFree(nodes);
+		if (nodes4) (void)hipFree(nodes4);
 		if (hot) (void)hipFree(hot);
 		if (cold) (void)hipFree(cold);
 	};
@@ -319,7 +359,8 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, void *stream_, Device
 	Box *node_box = (Box *)alloc(nn * sizeof(Box));
 	bool ok = boxes && scal && keys_a && keys_b && idx_a && idx_b && left && right && par_node && par_leaf && arrivals && node_depth && node_box;
 	ok = ok && hipMalloc(&nodes, (nn - 1) * sizeof(DevNode)) == hipSuccess && hipMalloc(&hot, nn * sizeof(TriHot) + 16) == hipSuccess &&
-			hipMalloc(&cold, nn * sizeof(TriCold)) == hipSuccess;
+			hipMalloc(&cold, nn * sizeof(TriCold)) == hipSuccess &&
+			(!want4 || hipMalloc(&nodes4, (nn - 1) * sizeof(Dev4Node)) == hipSuccess);
 	if (!ok) { std::snprintf(err, err_len, "device build: out of device memory"); cleanup(); return MRT_ERR_OOM; }
 
 	const uint32_t blocks = (uint32_t)((nn + LBVH_WG - 1) / LBVH_WG);
@@ -337,6 +378,7 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, void *stream_, Device
 	hipLaunchKernelGGL(lbvh_hierarchy_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, keys_b, n, left, right, par_node, par_leaf);
 	hipLaunchKernelGGL(lbvh_fit_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, n, boxes, idx_b, left, right, par_node, par_leaf,
 			arrivals, node_box, node_depth, nodes, scal + 6);
+	if (want4) hipLaunchKernelGGL(lbvh_collapse4_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes4);
 	hipLaunchKernelGGL(lbvh_leaves_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, d_tris, n, idx_b, hot, cold);
 	DB_TRY(hipGetLastError());
 	uint32_t h[8];
@@ -347,6 +389,8 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, void *stream_, Device
 	out->nodes = nodes; out->hot = hot; out->cold = cold;
 	out->n_nodes = n - 1; out->n_tris = n;
 	out->depth = h[6] + 1u; // pending entries on the deepest path + the sentinel
+	// 4-wide walk: every 4-wide node on a path leaves at most 3 entries pending and descends at least one binary level
+	out->nodes4 = nodes4; out->stack4 = nodes4 ? 3u * h[6] + 1u : 0u;
 	for (int k = 0; k < 3; k++) { out->bounds_lo[k] = ord2f(h[k]); out->bounds_hi[k] = ord2f(h[3 + k]); }
 	return MRT_OK;
 }

@@ -115,6 +115,28 @@ def test_c2_device_build_matches_host_build_on_the_full_grid(built):
     c.close()
 
 
+def test_c3_c4_device_build_matches_host_build(built):
+    """The headline scene (1 M triangles): 4096^2 primary rays (packet kernel) and 2^22 of C4's
+    incoherent rays (persistent lane kernel; 2-wide on the device-built tree, 4-wide on the
+    host-built one) give the same records against both trees."""
+    cfg = synth.CONFIGS["C3"]
+    w, h = cfg["grid"]
+    verts = synth.scene_vertices(cfg)
+    cam = capi.camera_look(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
+    c4 = synth.CONFIGS["C4"]
+    inc = synth.incoherent_rays(1 << 22, c4["ray_seed"])
+    c = capi.Context(0)
+    scene = capi.Scene(verts)
+    scene.upload(c)
+    host_grid = c.cast_grid(cam, w, h)
+    host_inc = c.cast(inc, flags=capi.FLAG_COHERENT)
+    c.build_scene_device(scene.tris)
+    assert c.cast_grid(cam, w, h).tobytes() == host_grid.tobytes()
+    assert c.cast(inc, flags=capi.FLAG_COHERENT).tobytes() == host_inc.tobytes()
+    assert c.cast(inc).tobytes() == host_inc.tobytes()      # Morton-sorted
+    c.close()
+
+
 def test_instances_flattened_and_built_on_the_device(built):
     """mrt_flatten_instances == the host flatten of RayTracerServer::_rebuild_scene + the Triangle
     ctor, bit for bit (meshes shared by several instances, per-mesh layer masks, running ids), and

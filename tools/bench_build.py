@@ -39,6 +39,18 @@ def main():
             ts.append(ctx.stats()["last_trace_ms"])
         return float(np.median(ts))
 
+    inc = synth.incoherent_rays(1 << 22, 7)
+    d_inc, d_inc_hits = ctx.device_alloc(inc.nbytes), ctx.device_alloc(inc.shape[0] * 32)
+    ctx.h2d(d_inc, inc)
+
+    def incoherent_ms():
+        ts = []
+        for _ in range(a.rounds):
+            ctx.cast(d_inc, d_inc_hits, count=inc.shape[0],
+                     flags=capi.FLAG_COHERENT | capi.FLAG_RAYS_ON_DEVICE | capi.FLAG_HITS_ON_DEVICE)
+            ts.append(ctx.stats()["last_trace_ms"])
+        return float(np.median(ts))
+
     def digest():
         hits = np.zeros(w * h, dtype=T.HIT32)
         ctx.d2h(hits, d_hits)
@@ -52,7 +64,7 @@ def main():
     ctx.upload_scene(tris, nodes, prim_idx)
     t2 = time.perf_counter()
     out["host"] = dict(build_s=t1 - t0, upload_s=t2 - t1, threads=len(os.sched_getaffinity(0)),
-                       stack_need=ctx.scene_info()["stack_need"], trace_ms=trace_ms())
+                       stack_need=ctx.scene_info()["stack_need"], trace_ms=trace_ms(), incoherent_4M_ms=incoherent_ms())
     host_hits = digest()
 
     # device: triangles from host memory (PCIe included in wall time), and already resident
@@ -69,7 +81,8 @@ def main():
         ctx.build_scene_device(d_tris, n_tris=n, on_device=True)
         res.append(ctx.stats()["last_build_ms"])
     out["device"] = dict(build_ms_from_host_tris=float(np.median(devs)), wall_ms_from_host_tris=float(np.median(walls)) * 1e3,
-                         build_ms_resident_tris=float(np.median(res)), stack_need=ctx.scene_info()["stack_need"], trace_ms=trace_ms())
+                         build_ms_resident_tris=float(np.median(res)), stack_need=ctx.scene_info()["stack_need"], trace_ms=trace_ms(),
+                         incoherent_4M_ms=incoherent_ms())
     out["identical_hits"] = bool(digest().tobytes() == host_hits.tobytes())
     if cfg.get("scene") == "multi_mesh":
         # the same scene as placed meshes: flatten (Transform3D::xform + Triangle ctor) and build on the device
