@@ -47,6 +47,8 @@ def parse():
     ap.add_argument("--depth", type=int, default=2, choices=[1, 2],
                     help="frames in flight at N > 1: with 2 the exchange of frame k runs beside the tracing of frame k+1 "
                          "(double-buffered); every frame is complete on rank 0 when the timed region closes")
+    ap.add_argument("--root-share", default="auto",
+                    help="N > 1, token gather: fraction of its own view rank 0 traces itself (auto: 1 - 0.065 (N-1)); 1 = no balancing")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gather", action="store_true")
     ap.add_argument("--gather", default="tokens", choices=["tokens", "records"],
@@ -97,6 +99,10 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # MRT_BENCH_ONE_DEVICE=1: every rank on device 0 (rehearsing the N > 1 code path on a one-GPU box; needs a
+    # collective backend that accepts it)
+    if os.environ.get("MRT_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     # under torch.distributed.run (RANK set) the process group exists even for one rank; with
@@ -105,7 +111,13 @@ def main():
     use_dist = world > 1 or ("RANK" in os.environ and os.environ.get("MRT_REHEARSE_GATHER") == "1")
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+        # MRT_BENCH_BACKEND=gloo: rehearsal of the N > 1 path with every rank on one GPU (RCCL refuses that);
+        # the exchange then goes through host memory (sharded._gather) and the timing means nothing
+        backend = os.environ.get("MRT_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=device)
+        else:
+            dist.init_process_group(backend=backend)
 
     from messyerraytracer_amd import capi, synth, sharded
     cfg = synth.CONFIGS[a.config]
@@ -139,8 +151,25 @@ def main():
     job = None
     events = []  # pipelined frames: the cast is only queued (MRT_FLAG_ASYNC); timed with events on its stream
 
-    def tracer(y0, y1, out):
+    # Balanced mode (N > 1, tokens): rank 0 also rebuilds every view's records, so it keeps only part of
+    # its own view and the peers trace the rest of view 0 besides their own (sharded.BalancedViews).
+    root_share = 1.0
+    if world > 1 and a.gather == "tokens" and not a.no_gather:
+        # expansion of one view costs ~6.5 % of tracing one (0.14 ms against 2.2 ms); rank 0 expands N of them
+        root_share = max(0.3, 1.0 - 0.065 * (world - 1)) if a.root_share == "auto" else float(a.root_share)
+    balanced = use_dist and root_share < 1.0
+    foreign = {}  # view -> (first row, device rays) for rows of another rank's view this rank traces
+    if balanced:
+        for (view, y0, y1) in sharded.balanced_spans(world, h, root_share)[rank]:
+            if view != rank:
+                buf = torch.empty((y1 - y0) * w * 32, dtype=torch.uint8, device=device)
+                ctx.generate_grid(cams[view], w, h, y0, y1, buf)
+                foreign[view] = (y0, buf)
+
+    def tracer(y0, y1, out, view=None):
         tok = capi.FLAG_TOKEN_OUT if job.token_mode else 0
+        own = view is None or view == rank
+        rays_ptr = d_rays.data_ptr() + y0 * w * 32 if own else foreign[view][1].data_ptr() + (y0 - foreign[view][0]) * w * 32
         if job.depth > 1:
             if a.mode == "tiled":
                 raise SystemExit("--mode tiled is blocking: use --depth 1")
@@ -148,13 +177,13 @@ def main():
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(stream)
         if a.mode == "fused":
-            ctx.cast_grid(cam, w, h, y0=y0, y1=y1, hits=out, flags=capi.FLAG_HITS_ON_DEVICE | tok)
+            ctx.cast_grid(cam if own else cams[view], w, h, y0=y0, y1=y1, hits=out, flags=capi.FLAG_HITS_ON_DEVICE | tok)
         elif a.mode == "tiled":
             if tok:
                 raise SystemExit("--mode tiled writes records only: use --gather records")
-            ctx.cast_tiled(d_rays.data_ptr() + y0 * w * 32, out, w, y1 - y0)
+            ctx.cast_tiled(rays_ptr, out, w, y1 - y0)
         else:
-            ctx.cast(d_rays.data_ptr() + y0 * w * 32, out, count=(y1 - y0) * w, flags=dev_flags | tok)
+            ctx.cast(rays_ptr, out, count=(y1 - y0) * w, flags=dev_flags | tok)
         if job.depth > 1:
             e1.record(stream)
             events.append((e0, e1))
@@ -169,8 +198,13 @@ def main():
             ctx.expand_grid_tokens(cams[view], w, h, y0, y1, tokens, hits, stream=stream)
 
     chunks = a.chunks if use_dist else 1
-    job = sharded.ShardedViews(w, h, tracer, device, chunks=chunks, gather=not a.no_gather, force_gather=use_dist,
-                               expander=expander if a.gather == "tokens" else None, depth=a.depth)
+    if balanced:
+        chunks = 1
+        job = sharded.BalancedViews(w, h, lambda view, y0, y1, out: tracer(y0, y1, out, view), expander, device,
+                                    root_share=root_share, depth=a.depth)
+    else:
+        job = sharded.ShardedViews(w, h, tracer, device, chunks=chunks, gather=not a.no_gather, force_gather=use_dist,
+                                   expander=expander if a.gather == "tokens" else None, depth=a.depth)
 
     def sync():
         if use_dist:
@@ -190,9 +224,19 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if use_dist:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    if rank == 0 and os.environ.get("MRT_BENCH_VERIFY") == "1" and use_dist and not a.no_gather:
+        # rehearsal aid: every view assembled on rank 0 must equal a direct cast of that view on this device
+        images = job.images if balanced else (job.images[0] if job.token_mode else job.images[(job.frame - 1) % job.depth])
+        direct = torch.empty(n_rays * 32, dtype=torch.uint8, device=device)
+        for v in range(world):
+            ctx.cast_grid(cams[v], w, h, hits=direct, flags=capi.FLAG_HITS_ON_DEVICE)
+            if not torch.equal(images[v], direct):
+                raise SystemExit(f"view {v} assembled on rank 0 differs from a direct cast")
+        print(f"verified {world} views on rank 0", file=sys.stderr, flush=True)
 
     if rank == 0:
         total_rays = n_rays * world * a.steps
@@ -206,19 +250,23 @@ def main():
                        "views": world, "gather": "none" if not (use_dist and not a.no_gather) else
                        ("rccl gather of 4-byte hit tokens to rank 0 in %d chunks, 32-byte records rebuilt there" % chunks
                         if job.token_mode else "rccl gather of 32-byte records to rank 0 in %d chunks" % chunks),
-                       "frames_in_flight": job.depth},
+                       "frames_in_flight": job.depth,
+                       "balance": ("rank 0 traces %.0f %% of its view (it also rebuilds every view's records); the other ranks "
+                                   "share the rest besides their own views" % (100 * root_share)) if balanced else "one view per rank"},
         }
         # roofline of the dominant kernel (trace_lane_kernel): algorithmic bytes / kernel time
         stats_path = os.path.join(ROOT, "tests", "golden", "traversal_stats.json")
         if events:  # queued casts: detection kernel + trace kernel between the two events
             trace_ms.extend(e0.elapsed_time(e1) for (e0, e1) in events)
         kernel_ms = float(np.sum(trace_ms)) / a.steps          # per step (all chunks), rank 0
+        # rays rank 0 itself traces per step (balanced mode: part of its view)
+        rank0_rays = sum(y1 - y0 for (_, y0, y1) in job.spans[0]) * w if balanced else n_rays
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-                "kernel": "trace_packet_asm_kernel<false>", "kernel_ms": kernel_ms}
+                "kernel": "trace_packet_asm_kernel<false>", "kernel_ms": kernel_ms, "rays_per_step_rank0": rank0_rays}
         if os.path.exists(stats_path):
             st = json.load(open(stats_path)).get(a.config)
             if st:
-                bytes_per_launch = st["bytes_per_ray"] * n_rays
+                bytes_per_launch = st["bytes_per_ray"] * rank0_rays
                 roof.update(achieved=bytes_per_launch / (kernel_ms * 1e-3) / 1e9, bytes_per_ray=st["bytes_per_ray"],
                             n_int=st["n_int"], n_tri=st["n_tri"])
                 roof["frac"] = roof["achieved"] / HBM_PEAK_GBS
@@ -226,7 +274,7 @@ def main():
         if os.path.exists(pmc):
             roof["traffic"] = json.load(open(pmc)).get(a.config, {}).get("hbm_bytes_per_launch")
         out["roofline"] = roof
-        out["kernel_only_mrays"] = n_rays / (kernel_ms * 1e-3) / 1e6
+        out["kernel_only_mrays"] = rank0_rays / (kernel_ms * 1e-3) / 1e6
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, verts)
         print(json.dumps(out), flush=True)

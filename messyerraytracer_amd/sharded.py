@@ -39,6 +39,25 @@ def chunk_bounds(y0: int, y1: int, chunks: int) -> List[Tuple[int, int]]:
     return [(y0 + c * n // chunks, y0 + (c + 1) * n // chunks) for c in range(chunks)]
 
 
+class _Done:
+    def wait(self):
+        return True
+
+
+def _gather(out: torch.Tensor, dst, group):
+    """dist.gather(async_op=True) to rank 0.  With a gloo group and device tensors -- several ranks
+    rehearsing on ONE GPU, which RCCL refuses -- the same exchange goes through host memory."""
+    if out.is_cuda and dist.get_backend(group) == "gloo":
+        host = out.cpu()
+        parts = [torch.empty_like(host) for _ in dst] if dst is not None else None
+        dist.gather(host, parts, dst=0, group=group)
+        if dst is not None:
+            for d, p in zip(dst, parts):
+                d.copy_(p)
+        return _Done()
+    return dist.gather(out, dst, dst=0, group=group, async_op=True)
+
+
 class _SideStream:
     """Where rank 0 expands tokens: a second HIP stream on a GPU (expansion of chunk c runs
     beside the tracing of chunk c+1), nothing on the CPU (gloo tests)."""
@@ -144,7 +163,7 @@ class ShardedGrid:
                         ry0, _ = row_block(r, self.world, self.rows)
                         spans.append((ry0 + (c0 - self.y0), ry0 + (c1 - self.y0)))
                     dst_list = [self._rows(self.staged, self.xrow_bytes, a, b, 0) for (a, b) in spans]
-                work = dist.gather(out, dst_list, dst=0, group=self.group, async_op=True)
+                work = _gather(out, dst_list, self.group)
                 if self.side is not None:
                     self._expand([work], spans)
                 else:
@@ -234,7 +253,7 @@ class ShardedViews:
             dst = None
             if self.rank == 0:
                 dst = [self.staged[b, r, c0 * self.xrow_bytes:c1 * self.xrow_bytes] for r in range(self.world)]
-            work = dist.gather(out, dst, dst=0, group=self.group, async_op=True)
+            work = _gather(out, dst, self.group)
             self.in_flight[b].append(work)
             if self.side is None:
                 continue
@@ -258,5 +277,93 @@ class ShardedViews:
         """Wait (stream-wise) for every queued exchange and expansion."""
         for b in range(self.depth):
             self._drain(b)
+        if self.side is not None:
+            self.side.join()
+
+
+def balanced_spans(world: int, rows: int, root_share: float) -> List[List[Tuple[int, int, int]]]:
+    """spans[r] = the (view, y0, y1) row ranges rank r traces when rank 0 keeps only the first
+    `root_share` of its own view and the other ranks share the rest of it (each still traces
+    its whole own view).  root_share = 1: every rank traces exactly its own view."""
+    if world == 1 or root_share >= 1.0:
+        return [[(r, 0, rows)] for r in range(world)]
+    keep = max(1, min(rows, int(round(rows * root_share))))
+    rest = rows - keep
+    spans = [[(0, 0, keep)]]
+    for r in range(1, world):
+        a, b = keep + rest * (r - 1) // (world - 1), keep + rest * r // (world - 1)
+        spans.append([(r, 0, rows)] + ([(0, a, b)] if b > a else []))
+    return spans
+
+
+class BalancedViews:
+    """The weak-scaling workload of ShardedViews (one view per rank, all views assembled as
+    records on rank 0, 4-byte tokens on the wire, frames pipelined `depth` deep) with rank 0's
+    extra duty priced in: rank 0 rebuilds everybody's records (0.14 ms per 4096^2 view against
+    2.2 ms of tracing), so with 8 ranks it would finish a third later than the others.  It
+    therefore keeps only `root_share` of its own view's rows and the peers trace the rest of
+    that view besides their own (balanced_spans); every rank sends one equally sized token
+    payload per frame (its spans back to back, padded), rank 0 expands each span into the
+    image of the view it belongs to.
+
+    tracer(view, y0, y1, out): tokens of rows [y0, y1) of `view` into out (uint8 view);
+    expander(view, y0, y1, tokens, hits, stream): rank 0, records of those rows on `stream`."""
+
+    def __init__(self, width: int, rows: int, tracer: Callable, expander: Callable, device: torch.device,
+                 root_share: float = 1.0, group=None, depth: int = 2):
+        if not dist.is_initialized():
+            raise RuntimeError("BalancedViews needs an initialised process group (use ShardedViews without one)")
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.width, self.rows, self.tracer, self.expander, self.group = width, rows, tracer, expander, group
+        self.token_mode, self.gather = True, True
+        self.depth = max(1, min(int(depth), 2))
+        self.spans = balanced_spans(self.world, rows, root_share)
+        self.pay_rows = max(sum(y1 - y0 for (_, y0, y1) in s) for s in self.spans)
+        self.row_bytes, self.xrow_bytes = width * HIT_BYTES, width * TOKEN_BYTES
+        self.local = torch.zeros((self.depth, self.pay_rows * self.xrow_bytes), dtype=torch.uint8, device=device)
+        self.images = self.staged = self.side = None
+        if self.rank == 0:
+            self.staged = torch.empty((self.depth, self.world, self.pay_rows * self.xrow_bytes), dtype=torch.uint8, device=device)
+            self.images = torch.empty((self.world, rows * self.row_bytes), dtype=torch.uint8, device=device)
+            self.side = _SideStream(device)
+        self.frame = 0
+        self.in_flight = [None] * self.depth
+        self.expanded = [None] * self.depth
+
+    def step(self):
+        """Trace this rank's spans of one frame and queue the exchange.  Rank 0 gets the [view]
+        images (complete after finish() when depth > 1), the others None."""
+        b = self.frame % self.depth
+        self.frame += 1
+        if self.in_flight[b] is not None:
+            self.in_flight[b].wait()          # the exchange that last used this slot is done with it
+        if self.side is not None:
+            self.side.wait_mark(self.expanded[b])
+        local, off = self.local[b], 0
+        for (view, y0, y1) in self.spans[self.rank]:
+            self.tracer(view, y0, y1, local[off * self.xrow_bytes:(off + y1 - y0) * self.xrow_bytes])
+            off += y1 - y0
+        dst = [self.staged[b, r] for r in range(self.world)] if self.rank == 0 else None
+        work = _gather(local, dst, self.group)
+        self.in_flight[b] = work
+        if self.rank == 0:
+            def fn(stream, b=b):
+                for r in range(self.world):
+                    o = 0
+                    for (view, y0, y1) in self.spans[r]:
+                        self.expander(view, y0, y1, self.staged[b, r, o * self.xrow_bytes:(o + y1 - y0) * self.xrow_bytes],
+                                      self.images[view, y0 * self.row_bytes:y1 * self.row_bytes], stream)
+                        o += y1 - y0
+            self.side.run_after([work], fn)
+            self.expanded[b] = self.side.mark()
+        if self.depth == 1:
+            self.finish()
+        return self.images if self.rank == 0 else None
+
+    def finish(self):
+        for b in range(self.depth):
+            if self.in_flight[b] is not None:
+                self.in_flight[b].wait()
+                self.in_flight[b] = None
         if self.side is not None:
             self.side.join()

@@ -131,3 +131,72 @@ def test_single_process_is_a_plain_loop():
     job = sharded.ShardedGrid(8, 10, tracer, torch.device("cpu"), chunks=3)
     img = job.step()
     assert calls == sharded.chunk_bounds(0, 10, 3) and img.numel() == 10 * 8 * 32 and bool((img == 7).all())
+
+
+def _balanced_worker(rank, world, port, width, rows, share, depth, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    frame = [0]
+    traced = []
+
+    def tracer(view, y0, y1, out):
+        traced.append((view, y0, y1))
+        rec = _pattern(y0, y1, width, view, 1000 * frame[0])
+        out.copy_(torch.from_numpy(np.ascontiguousarray(rec[..., 2]).view(np.uint8).reshape(-1)))
+
+    def rebuild(view, y0, y1, tok, hits, stream):
+        rec = _pattern(y0, y1, width, view)
+        rec[..., 2] = tok.numpy().view(np.uint32).reshape(y1 - y0, width)
+        hits.copy_(torch.from_numpy(rec.view(np.uint8).reshape(-1)))
+
+    job = sharded.BalancedViews(width, rows, tracer, rebuild, torch.device("cpu"), root_share=share, depth=depth)
+    for k in range(3):
+        traced.clear()
+        frame[0] = k
+        img = job.step()
+    job.finish()
+    ok = traced == job.spans[rank]
+    if rank == 0:
+        got = img.numpy()
+        for v in range(world):
+            ok = ok and np.array_equal(got[v], _pattern(0, rows, width, v, 2000).view(np.uint8).reshape(-1))
+    else:
+        ok = ok and img is None
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("width,rows,share,depth", [(16, 20, 0.6, 2), (8, 7, 0.3, 1), (8, 9, 1.0, 2)])
+def test_balanced_views_world_size_2(width, rows, share, depth):
+    """Rank 0 keeps `share` of its view, rank 1 traces the rest besides its own view; rank 0
+    still ends up with every view complete."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_balanced_worker, args=(r, 2, port, width, rows, share, depth, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}
+
+
+def test_balanced_spans_cover_every_view_once():
+    for world in (1, 2, 3, 8):
+        for rows in (1, 5, 4096):
+            for share in (1.0, 0.55, 0.01):
+                spans = sharded.balanced_spans(world, rows, share)
+                assert len(spans) == world
+                cover = {v: [] for v in range(world)}
+                for s in spans:
+                    for (v, a, b) in s:
+                        assert 0 <= a < b <= rows
+                        cover[v].append((a, b))
+                for v, parts in cover.items():
+                    parts.sort()
+                    assert parts[0][0] == 0 and parts[-1][1] == rows
+                    assert all(parts[i][1] == parts[i + 1][0] for i in range(len(parts) - 1))
