@@ -11,7 +11,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <string.h>
+#include <atomic>
 #include <new>
+#include <thread>
 #include <vector>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -54,6 +56,9 @@ struct mrt_ctx {
 	DevBuf rays, hits, keys_in, keys_out, idx_in, idx_out, sort_tmp, overflow;
 	int cu_count = 256;
 	unsigned long long *d_counters = nullptr;
+	// host-array pipeline (cast_host_pipelined): copy streams and per-chunk events, created on first use
+	hipStream_t up_stream = nullptr, dn_stream = nullptr;
+	std::vector<hipEvent_t> pipe_ev;
 	// async state
 	bool pending = false;
 	uint64_t pending_count = 0; uint32_t pending_flags = 0; int pending_mode = 0;
@@ -304,6 +309,68 @@ int finish_timing(mrt_ctx *ctx, bool h2d, bool sorted, bool d2h)
 	return MRT_OK;
 }
 
+// Host arrays in, host arrays out (the reference's cast_rays contract), large batch: upload, trace and
+// download run as a pipeline over 2^20-ray chunks.  A pageable copy occupies the host thread that
+// issues it, so uploads are issued from the calling thread and downloads from a helper thread: both
+// PCIe directions then move data at once, and the trace of a chunk hides between them.
+constexpr uint64_t kPipeChunk = 1ull << 20;
+
+int cast_host_pipelined(mrt_ctx *ctx, const void *rays, void *hits, uint64_t count, uint32_t query_mask, int mode, uint32_t flags)
+{
+	const size_t rs = ray_stride(flags), hs = hit_stride(flags, mode);
+	const uint32_t n_chunks = (uint32_t)((count + kPipeChunk - 1) / kPipeChunk);
+	int rc;
+	if ((rc = ensure(ctx, ctx->rays, count * rs)) || (rc = ensure(ctx, ctx->hits, count * hs))) return rc;
+	if (!ctx->up_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->up_stream, hipStreamNonBlocking));
+	if (!ctx->dn_stream) HIP_TRY(ctx, hipStreamCreateWithFlags(&ctx->dn_stream, hipStreamNonBlocking));
+	while (ctx->pipe_ev.size() < 2u * n_chunks) {
+		hipEvent_t e;
+		HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		ctx->pipe_ev.push_back(e);
+	}
+	char *d_rays = (char *)ctx->rays.ptr, *d_hits = (char *)ctx->hits.ptr;
+	std::atomic<uint32_t> traced{0};      // chunks whose trace has been queued (their event is recorded)
+	std::atomic<int> stop{0}, down_err{0};
+	std::thread down([&] {
+		if (hipSetDevice(ctx->device) != hipSuccess) { down_err = (int)hipErrorInvalidDevice; return; }
+		for (uint32_t k = 0; k < n_chunks; k++) {
+			while (traced.load(std::memory_order_acquire) <= k) { if (stop.load()) return; std::this_thread::yield(); }
+			const uint64_t off = (uint64_t)k * kPipeChunk, n = count - off < kPipeChunk ? count - off : kPipeChunk;
+			hipError_t e = hipEventSynchronize(ctx->pipe_ev[2 * k + 1]);
+			if (e == hipSuccess) e = hipMemcpyAsync((char *)hits + off * hs, d_hits + off * hs, n * hs, hipMemcpyDeviceToHost, ctx->dn_stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(ctx->dn_stream);
+			if (e != hipSuccess) { down_err = (int)e; return; }
+		}
+	});
+	const uint32_t dev_flags = flags | MRT_FLAG_RAYS_ON_DEVICE | MRT_FLAG_HITS_ON_DEVICE;
+	hipError_t e = hipSuccess;
+	uint32_t launches = 0;
+	for (uint32_t k = 0; k < n_chunks && e == hipSuccess && rc == MRT_OK && !down_err.load(); k++) {
+		const uint64_t off = (uint64_t)k * kPipeChunk, n = count - off < kPipeChunk ? count - off : kPipeChunk;
+		e = hipMemcpyAsync(d_rays + off * rs, (const char *)rays + off * rs, n * rs, hipMemcpyHostToDevice, ctx->up_stream);
+		if (e == hipSuccess) e = hipEventRecord(ctx->pipe_ev[2 * k], ctx->up_stream);
+		if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->pipe_ev[2 * k], 0);
+		if (e != hipSuccess) break;
+		void *unused = nullptr;
+		rc = enqueue_cast(ctx, d_rays + off * rs, d_hits + off * hs, n, query_mask, mode, dev_flags, &unused);
+		if (rc) break;
+		if (ctx->stats.last_kernel_launches > launches) launches = ctx->stats.last_kernel_launches;
+		e = hipEventRecord(ctx->pipe_ev[2 * k + 1], ctx->stream);
+		if (e == hipSuccess) traced.store(k + 1, std::memory_order_release);
+	}
+	if (e != hipSuccess || rc != MRT_OK) stop = 1;
+	down.join();
+	(void)hipStreamSynchronize(ctx->stream);
+	if (rc) return rc;
+	if (e != hipSuccess || down_err.load()) {
+		std::snprintf(ctx->err, sizeof(ctx->err), "pipelined cast failed: %s", hipGetErrorString(e != hipSuccess ? e : (hipError_t)down_err.load()));
+		return MRT_ERR_HIP;
+	}
+	ctx->stats.last_kernel_launches = launches;
+	ctx->stats.last_h2d_ms = ctx->stats.last_d2h_ms = 0.0f; // overlapped: not separable (last_trace_ms is the last chunk's)
+	return finish_timing(ctx, false, launches >= 2, false);
+}
+
 } // namespace
 
 extern "C" {
@@ -367,6 +434,9 @@ void mrt_destroy(mrt_ctx *ctx)
 	release(ctx->idx_in); release(ctx->idx_out); release(ctx->sort_tmp); release(ctx->overflow);
 	if (ctx->d_counters) (void)hipFree(ctx->d_counters);
 	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
+	for (auto &e : ctx->pipe_ev) (void)hipEventDestroy(e);
+	if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
+	if (ctx->dn_stream) (void)hipStreamDestroy(ctx->dn_stream);
 	if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
 	delete ctx;
 }
@@ -572,6 +642,10 @@ int mrt_cast(mrt_ctx *ctx, const void *rays, void *hits, uint64_t count, uint32_
 	const bool hits_dev = (flags & MRT_FLAG_HITS_ON_DEVICE) != 0;
 	if ((flags & MRT_FLAG_ASYNC) && !(hits_dev && (flags & MRT_FLAG_RAYS_ON_DEVICE)))
 		return fail(ctx, MRT_ERR_INVALID, "ASYNC needs device-resident rays and hits");
+	if (!hits_dev && !(flags & MRT_FLAG_RAYS_ON_DEVICE) && count >= 2 * kPipeChunk && !ctx->opts.count_visits) {
+		if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded (is_available() == false)");
+		return cast_host_pipelined(ctx, rays, hits, count, query_mask, mode, flags);
+	}
 	int rc = enqueue_cast(ctx, rays, hits_dev ? hits : nullptr, count, query_mask, mode, flags, &d_hits);
 	if (rc) return rc;
 	if (flags & MRT_FLAG_ASYNC) return MRT_OK; // queued on the context's stream; no timing

@@ -153,6 +153,24 @@ __device__ __forceinline__ void store_hit(const TraceParams &p, uint64_t idx, co
 	q[0] = a; q[1] = b;
 }
 
+// End of a ray in every kernel: look up what the record needs about the winning triangle (id,
+// layers, the cold normal row) and store it.  Bool and token outputs need none of that.
+__device__ __forceinline__ void finish_ray(const TraceParams &p, uint64_t ray_idx, const RayRegs &r,
+		float best_t, float best_u, float best_v, uint32_t best_slot)
+{
+	int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
+	if (best_slot != 0xFFFFFFFFu) {
+		if (p.out_fmt == OUT_BOOL8 || p.out_fmt == OUT_TOKEN4) prim = 0; // only "hit or not" (and the slot) is stored
+		else {
+			prim = (int32_t)p.tri_hot[best_slot].id;
+			layers = p.tri_hot[best_slot].layers;
+			const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
+			nx = nn.x; ny = nn.y; nz = nn.z;
+		}
+	}
+	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
+}
+
 // ---- the traversal kernel: one lane = one ray -------------------------------------
 // LDS: per-lane stack, entry d of lane l at dword d*64 + l of the wave's region
 // (conflict-free: the 64 lanes of a push/pop hit 64 consecutive dwords).
@@ -260,20 +278,13 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 	}
 
 	// ---- result: glsl:322-327 ----
-	int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
-	if (best_slot != 0xFFFFFFFFu) {
-		prim = (int32_t)p.tri_hot[best_slot].id;
-		layers = p.tri_hot[best_slot].layers;
-		const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
-		nx = nn.x; ny = nn.y; nz = nn.z;
-	}
-	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
+	finish_ray(p, ray_idx, r, best_t, best_u, best_v, best_slot);
 
 	if (COUNT) {
 		atomicAdd(&p.counters[0], 1ull);
 		atomicAdd(&p.counters[1], (unsigned long long)n_tris);
 		atomicAdd(&p.counters[2], (unsigned long long)n_nodes);
-		if (prim >= 0) atomicAdd(&p.counters[3], 1ull);
+		if (best_slot != 0xFFFFFFFFu) atomicAdd(&p.counters[3], 1ull);
 		atomicMax(&p.counters[4], (unsigned long long)max_sp);
 	}
 }
@@ -550,14 +561,12 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		return hipGetLastError();
 	}
 	if (p.kernel == MRT_KERNEL_PACKET || p.kernel == MRT_KERNEL_PACKET_ASM) {
-		// experiment knob: extra (unused) dynamic LDS per workgroup lowers the occupancy
-		static const size_t pad = [] { const char *e = getenv("MRT_EXP_LDS_PAD"); return e ? (size_t)atol(e) : (size_t)0; }();
 		if (any_hit) {
-			if (count) hipLaunchKernelGGL((trace_packet_kernel<true, true>), grid, wg, pad, stream, p);
-			else hipLaunchKernelGGL((trace_packet_kernel<true, false>), grid, wg, pad, stream, p);
+			if (count) hipLaunchKernelGGL((trace_packet_kernel<true, true>), grid, wg, 0, stream, p);
+			else hipLaunchKernelGGL((trace_packet_kernel<true, false>), grid, wg, 0, stream, p);
 		} else {
-			if (count) hipLaunchKernelGGL((trace_packet_kernel<false, true>), grid, wg, pad, stream, p);
-			else hipLaunchKernelGGL((trace_packet_kernel<false, false>), grid, wg, pad, stream, p);
+			if (count) hipLaunchKernelGGL((trace_packet_kernel<false, true>), grid, wg, 0, stream, p);
+			else hipLaunchKernelGGL((trace_packet_kernel<false, false>), grid, wg, 0, stream, p);
 		}
 		return hipGetLastError();
 	}

@@ -88,14 +88,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 		// ---- retire finished lanes, hand out new rays ----
 		const bool idle = cur == kSentinel;
 		if (idle && has_ray) {
-			int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
-			if (best_slot != 0xFFFFFFFFu) {
-				prim = (int32_t)p.tri_hot[best_slot].id;
-				layers = p.tri_hot[best_slot].layers;
-				const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
-				nx = nn.x; ny = nn.y; nz = nn.z;
-			}
-			store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
+			finish_ray(p, ray_idx, r, best_t, best_u, best_v, best_slot);
 			has_ray = false;
 		}
 		const unsigned long long idle_mask = __ballot(idle);

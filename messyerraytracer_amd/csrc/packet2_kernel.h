@@ -158,20 +158,13 @@ __device__ __forceinline__ void pkt2_finish(const TraceParams &p, const Pkt2 &k,
 		uint32_t n_nodes, uint32_t n_tris)
 {
 	if (!valid) return;
-	int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
-	if (k.best_slot != 0xFFFFFFFFu) {
-		prim = (int32_t)p.tri_hot[k.best_slot].id;
-		layers = p.tri_hot[k.best_slot].layers;
-		const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[k.best_slot];
-		nx = nn.x; ny = nn.y; nz = nn.z;
-	}
 	RayRegs r = k.r;
-	store_hit(p, ray_idx, r, k.best_t, prim, k.best_u, k.best_v, nx, ny, nz, layers, k.best_slot);
+	finish_ray(p, ray_idx, r, k.best_t, k.best_u, k.best_v, k.best_slot);
 	if (count) {
 		atomicAdd(&p.counters[0], 1ull);
 		atomicAdd(&p.counters[1], (unsigned long long)n_tris);
 		atomicAdd(&p.counters[2], (unsigned long long)n_nodes);
-		if (prim >= 0) atomicAdd(&p.counters[3], 1ull);
+		if (k.best_slot != 0xFFFFFFFFu) atomicAdd(&p.counters[3], 1ull);
 	}
 }
 

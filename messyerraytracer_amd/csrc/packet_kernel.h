@@ -161,20 +161,13 @@ __global__ __launch_bounds__(MRT_WG) void trace_packet_kernel(const TraceParams 
 	}
 #undef MRT_PKT
 
-	int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
-	if (best_slot != 0xFFFFFFFFu) {
-		prim = (int32_t)p.tri_hot[best_slot].id;
-		layers = p.tri_hot[best_slot].layers;
-		const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
-		nx = nn.x; ny = nn.y; nz = nn.z;
-	}
-	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
+	finish_ray(p, ray_idx, r, best_t, best_u, best_v, best_slot);
 
 	if (COUNT) { // wave-level counts: each wave-step is charged to every live lane
 		atomicAdd(&p.counters[0], 1ull);
 		atomicAdd(&p.counters[1], (unsigned long long)n_tris);
 		atomicAdd(&p.counters[2], (unsigned long long)n_nodes);
-		if (prim >= 0) atomicAdd(&p.counters[3], 1ull);
+		if (best_slot != 0xFFFFFFFFu) atomicAdd(&p.counters[3], 1ull);
 		atomicAdd(&p.counters[5], (unsigned long long)n_dead);
 	}
 }

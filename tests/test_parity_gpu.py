@@ -569,6 +569,40 @@ def test_c2_full(ctx):
     assert got44.tobytes() == po.unpack_hits(want, host).tobytes()
 
 
+def test_host_arrays_pipelined_in_chunks(ctx):
+    """Host arrays of >= 2^21 rays (the reference's cast_rays contract at scale) go through the
+    upload / trace / download pipeline in 2^20-ray chunks with a ragged tail: the records must equal
+    those of one device-resident cast, for packed and 60/44-byte layouts, coherent, sorted and any-hit."""
+    cfg = synth.CONFIGS["C2"]
+    verts = synth.scene_vertices(cfg)
+    scene = capi.Scene(verts)
+    scene.upload(ctx)
+    w, h = 2048, 1100                                   # 2 252 800 rays: two full chunks and a part of one
+    cam = capi.camera_look(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
+    want = ctx.cast_grid(cam, w, h)
+    rays = po.grid_rays(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
+    n = rays.shape[0]
+    assert n >= 2 * (1 << 20) and n % (1 << 20) != 0
+    got = ctx.cast(rays, flags=capi.FLAG_COHERENT)
+    assert got.tobytes() == want.tobytes()
+    assert ctx.cast(rays).tobytes() == want.tobytes()    # every chunk Morton-sorted on the device
+    host = po.make_host_rays(rays)
+    got44 = ctx.cast(host, flags=capi.FLAG_COHERENT | capi.FLAG_HOST_LAYOUT)
+    assert got44.tobytes() == po.unpack_hits(want, host).tobytes()
+    b = ctx.cast(rays, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_COHERENT | capi.FLAG_BOOL_OUT)
+    assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
+    tok = ctx.cast(rays, flags=capi.FLAG_COHERENT | capi.FLAG_TOKEN_OUT)
+    assert np.array_equal(tok != capi.TOKEN_MISS, want["prim_id"] >= 0)
+    inc = synth.incoherent_rays(n, 123)
+    osc = po.OracleScene(verts)
+    got_inc = ctx.cast(inc)
+    parity.assert_exact(got_inc[:100000], osc.trace(inc[:100000]), "pipelined incoherent, first 100k")
+    parity.assert_exact(got_inc[-50000:], osc.trace(inc[-50000:]), "pipelined incoherent, ragged tail")
+    assert ctx.stats()["rays_cast"] > 0
+    with pytest.raises(capi.MrtError):                   # errors of a chunk surface as errors of the cast
+        ctx.cast(rays, mode=7)
+
+
 def test_c3_full_headline(ctx):
     """Config C3 (headline): 1 M-triangle soup, 4096^2 primary rays."""
     _full_grid_case(ctx, "C3", (2040, 2056))
