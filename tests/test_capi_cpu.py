@@ -42,6 +42,13 @@ def test_null_arguments_are_rejected_not_crashed(built):
     assert L.mrt_create(0, None, None) == capi.ERR_INVALID
     assert L.mrt_cast(None, None, None, 0, 0, 0, 0) == capi.ERR_INVALID
     assert L.mrt_has_pending(None) == 0 and L.mrt_is_available(None) == 0
+    # the entry points added for the device-side build, instancing and the token exchange
+    assert L.mrt_build_scene_device(None, None, 0, 0) == capi.ERR_INVALID
+    assert L.mrt_flatten_instances(None, None, 0, None, 0, 0, None) == capi.ERR_INVALID
+    assert L.mrt_build_instanced_scene_device(None, None, 0, None, 0, 0) == capi.ERR_INVALID
+    assert L.mrt_expand_tokens(None, None, None, None, 0, 0, None) == capi.ERR_INVALID
+    assert L.mrt_expand_grid_tokens(None, None, 0, 0, 0, 0, None, None, None) == capi.ERR_INVALID
+    assert C.sizeof(capi.Stats) == 80 and T.INSTANCE.itemsize == 64
     L.mrt_destroy(None)  # no-op
 
 

@@ -46,6 +46,10 @@ VARIANTS = {
     "asm_fused": (dict(kernel=capi.KERNEL_PACKET_ASM), "fused"),
     "auto_cast": (dict(), "cast"),
     "auto_tiled": (dict(), "tiled"),
+    "persist2_linear": (dict(kernel=capi.KERNEL_LANE_PERSISTENT), "cast"),
+    "persist4_linear": (dict(kernel=capi.KERNEL_LANE4_PERSISTENT), "cast"),
+    "persist4_linear_l32": (dict(kernel=capi.KERNEL_LANE4_PERSISTENT, leaf_wait=32), "cast"),
+    "persist4_linear_l8": (dict(kernel=capi.KERNEL_LANE4_PERSISTENT, leaf_wait=8), "cast"),
 }
 
 
