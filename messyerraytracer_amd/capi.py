@@ -21,7 +21,7 @@ FLAG_COHERENT, FLAG_RAYS_ON_DEVICE, FLAG_HITS_ON_DEVICE, FLAG_HOST_LAYOUT, FLAG_
 TOKEN_MISS = 0xFFFFFFFF
 BUILD_TRIS_ON_DEVICE = 1
 KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET, KERNEL_PACKET4, KERNEL_PACKET2, KERNEL_PACKET_ASM, KERNEL_LANE_PERSISTENT, \
-    KERNEL_LANE4_PERSISTENT = range(8)
+    KERNEL_LANE4_PERSISTENT, KERNEL_LANE8_PERSISTENT = range(9)
 
 # every entry point include/mrt_hip.h declares (tests check they are all exported)
 SYMBOLS = [

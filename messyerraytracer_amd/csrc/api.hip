@@ -49,6 +49,7 @@ struct mrt_ctx {
 	// scene
 	mrt::DevNode *d_nodes = nullptr; mrt::TriHot *d_hot = nullptr; mrt::TriCold *d_cold = nullptr;
 	mrt::Dev4Node *d_nodes4 = nullptr; uint32_t n_nodes4 = 0;
+	mrt::Dev8Node *d_nodes8 = nullptr; uint32_t n_nodes8 = 0, stack8 = 0;
 	float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
 	uint32_t n_nodes = 0, n_tris = 0, depth = 0, stack_depth = 0, stack4 = 0;
 	bool scene = false;
@@ -104,7 +105,9 @@ void free_scene(mrt_ctx *ctx)
 	if (ctx->d_hot) (void)hipFree(ctx->d_hot);
 	if (ctx->d_cold) (void)hipFree(ctx->d_cold);
 	if (ctx->d_nodes4) (void)hipFree(ctx->d_nodes4);
-	ctx->d_nodes = nullptr; ctx->d_hot = nullptr; ctx->d_cold = nullptr; ctx->d_nodes4 = nullptr;
+	if (ctx->d_nodes8) (void)hipFree(ctx->d_nodes8);
+	ctx->d_nodes = nullptr; ctx->d_hot = nullptr; ctx->d_cold = nullptr; ctx->d_nodes4 = nullptr; ctx->d_nodes8 = nullptr;
+	ctx->n_nodes8 = ctx->stack8 = 0;
 	ctx->scene = false; ctx->n_nodes = ctx->n_tris = 0;
 }
 
@@ -126,7 +129,7 @@ uint32_t out_format(uint32_t flags, int mode)
 void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 {
 	std::memset(&p, 0, sizeof(p));
-	p.nodes = ctx->d_nodes; p.nodes4 = ctx->d_nodes4; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold;
+	p.nodes = ctx->d_nodes; p.nodes4 = ctx->d_nodes4; p.nodes8 = ctx->d_nodes8; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold;
 	p.stack_depth = ctx->stack_depth; p.n_tris = ctx->n_tris;
 	if (ctx->opts.stack_override >= ctx->depth && ctx->opts.stack_override <= 64) p.stack_depth = ctx->opts.stack_override;
 	p.counters = ctx->d_counters;
@@ -142,7 +145,7 @@ uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent)
 {
 	// the 4-wide packet kernel keeps 128 stack entries per wave; a device-built tree only has a loose bound
 	if (ctx->opts.kernel == MRT_KERNEL_PACKET4 && (!ctx->d_nodes4 || ctx->stack4 > 128u)) return MRT_KERNEL_PACKET;
-	if (ctx->opts.kernel >= MRT_KERNEL_LANE && ctx->opts.kernel <= MRT_KERNEL_LANE4_PERSISTENT) return ctx->opts.kernel;
+	if (ctx->opts.kernel >= MRT_KERNEL_LANE && ctx->opts.kernel <= MRT_KERNEL_LANE8_PERSISTENT) return ctx->opts.kernel;
 	// (PACKET4 halves the fetch chain but measured 7 % slower at C3: the walk is bound by
 	// instruction issue, and ordering four children costs more scalar work than it saves)
 	// PACKET_ASM: same walk with the hand-written node loop (the compiler's loop is scalar-ALU bound)
@@ -185,7 +188,10 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 	// persistent form only
 	const bool wide4 = ctx->d_nodes4 != nullptr && (ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
 			(ctx->opts.kernel == MRT_KERNEL_AUTO && persistent));
-	if (wide4 && !ctx->opts.count_visits) persistent = true;
+	// the 8-wide compressed walk where the scene has that layout (host-built scenes): 6.5 against 7.7 ms at C4
+	const bool wide8 = ctx->d_nodes8 != nullptr && (ctx->opts.kernel == MRT_KERNEL_LANE8_PERSISTENT ||
+			(ctx->opts.kernel == MRT_KERNEL_AUTO && persistent));
+	if ((wide4 || wide8) && !ctx->opts.count_visits) persistent = true;
 	if (!persistent || ctx->opts.count_visits) {
 		p.kernel = MRT_KERNEL_LANE;
 		HIP_TRY(ctx, mrt::launch_trace(p, any_hit, ctx->opts.count_visits != 0, ctx->stream));
@@ -198,17 +204,17 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 	const uint64_t needed = (count + 255u) / 256u;
 	if (blocks > needed) blocks = needed;
 	uint32_t *ovf = nullptr;
-	const uint32_t need = wide4 ? ctx->stack4 : ctx->depth; // entries one ray can have pending
+	const uint32_t need = wide8 ? ctx->stack8 : (wide4 ? ctx->stack4 : ctx->depth); // entries one ray can have pending
 	if (need > lds_depth) { // deeper entries spill to [depth - lds_depth][thread] in HBM
 		if ((rc = ensure(ctx, ctx->overflow, (size_t)(need - lds_depth) * blocks * 256u * 4u))) return rc;
 		ovf = (uint32_t *)ctx->overflow.ptr;
 	}
-	p.kernel = wide4 ? MRT_KERNEL_LANE4_PERSISTENT : MRT_KERNEL_LANE_PERSISTENT;
+	p.kernel = wide8 ? MRT_KERNEL_LANE8_PERSISTENT : (wide4 ? MRT_KERNEL_LANE4_PERSISTENT : MRT_KERNEL_LANE_PERSISTENT);
 	// eight ray counters (one per region of the batch), 128 bytes apart
 	unsigned long long *next_ray = ctx->d_counters + 16 + 1026;
 	HIP_TRY(ctx, hipMemsetAsync(next_ray, 0, 128 * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace_persistent(p, next_ray, ovf, lds_depth, ctx->opts.refill ? ctx->opts.refill : 16u,
-			ctx->opts.leaf_wait ? ctx->opts.leaf_wait : 16u, (uint32_t)blocks, any_hit, ctx->stream));
+			ctx->opts.leaf_wait ? ctx->opts.leaf_wait : (wide8 ? 8u : 16u), (uint32_t)blocks, any_hit, ctx->stream));
 	return MRT_OK;
 }
 
@@ -254,8 +260,9 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	// Coherent batch without a declared width: look for the row width on the device and let the
 	// trace kernel tile its lanes (no host round trip: the kernel reads the answer from HBM).
 	// Timed with the sort as pre-processing (last_sort_ms); last_trace_ms is the trace kernel alone.
-	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 4096 && ctx->opts.grid_tile != 1 &&
-			p.kernel != MRT_KERNEL_LANE_PERSISTENT && p.kernel != MRT_KERNEL_LANE4_PERSISTENT;
+	const bool persistent_kind = p.kernel == MRT_KERNEL_LANE_PERSISTENT || p.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
+			p.kernel == MRT_KERNEL_LANE8_PERSISTENT;
+	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 4096 && ctx->opts.grid_tile != 1 && !persistent_kind;
 	if (detect) {
 		uint32_t *d_auto = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);
 		HIP_TRY(ctx, mrt::launch_detect_grid(d_rays, p.in_fmt, count, p.tile_w_log2, ctx->d_counters + 16, d_auto, ctx->stream));
@@ -275,9 +282,8 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	} else {
 		// large incoherent batches: resident waves that pull rays from a counter (no counting variant)
 		const bool persistent = !ctx->opts.count_visits && p.lane_map == mrt::MAP_LINEAR &&
-				(p.kernel == MRT_KERNEL_LANE_PERSISTENT || p.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
-				 (ctx->opts.kernel == MRT_KERNEL_AUTO && p.kernel == MRT_KERNEL_LANE && count >= 65536));
-		if (p.kernel == MRT_KERNEL_LANE_PERSISTENT || p.kernel == MRT_KERNEL_LANE4_PERSISTENT || p.kernel == MRT_KERNEL_LANE) {
+				(persistent_kind || (ctx->opts.kernel == MRT_KERNEL_AUTO && p.kernel == MRT_KERNEL_LANE && count >= 65536));
+		if (persistent_kind || p.kernel == MRT_KERNEL_LANE) {
 			if ((rc = launch_lane(ctx, p, count, any, persistent))) return rc;
 		} else HIP_TRY(ctx, mrt::launch_trace(p, any, ctx->opts.count_visits != 0, ctx->stream));
 	}
@@ -465,9 +471,10 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	int rc = drain_pending(ctx); // gpu_ray_caster.cpp:198-202
 	if (rc) return rc;
 	mrt::DeviceSceneHost h;
+	h.want8 = ctx->opts.kernel == MRT_KERNEL_LANE8_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_AUTO;
 	rc = mrt::prepare_scene(tris, n_tris, nodes, used_nodes, prim_idx, &h, ctx->err, sizeof(ctx->err));
 	if (rc) return rc;
-	auto cleanup = [&] { std::free(h.nodes); std::free(h.nodes4); std::free(h.hot); std::free(h.cold); };
+	auto cleanup = [&] { std::free(h.nodes); std::free(h.nodes4); std::free(h.nodes8); std::free(h.hot); std::free(h.cold); };
 	if (h.depth > 64 || h.stack4 > 128) { cleanup(); return fail(ctx, MRT_ERR_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack"); }
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	free_scene(ctx);
@@ -479,7 +486,8 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 			// +16 B: the dual-packet kernel fetches 64 B at a 48-B triangle (the tail is never used)
 			(e = hipMalloc(&ctx->d_hot, (size_t)h.n_tris * sizeof(mrt::TriHot) + 16)) != hipSuccess ||
 			(e = hipMalloc(&ctx->d_cold, (size_t)h.n_tris * sizeof(mrt::TriCold))) != hipSuccess ||
-			(want4 && (e = hipMalloc(&ctx->d_nodes4, (size_t)h.n_nodes4 * sizeof(mrt::Dev4Node))) != hipSuccess)) {
+			(want4 && (e = hipMalloc(&ctx->d_nodes4, (size_t)h.n_nodes4 * sizeof(mrt::Dev4Node))) != hipSuccess) ||
+			(h.nodes8 && (e = hipMalloc(&ctx->d_nodes8, (size_t)h.n_nodes8 * sizeof(mrt::Dev8Node))) != hipSuccess)) {
 		cleanup(); free_scene(ctx);
 		return fail(ctx, MRT_ERR_OOM, "scene does not fit in device memory");
 	}
@@ -487,7 +495,9 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	if (e == hipSuccess) e = hipMemcpy(ctx->d_hot, h.hot, (size_t)h.n_tris * sizeof(mrt::TriHot), hipMemcpyHostToDevice);
 	if (e == hipSuccess) e = hipMemcpy(ctx->d_cold, h.cold, (size_t)h.n_tris * sizeof(mrt::TriCold), hipMemcpyHostToDevice);
 	if (e == hipSuccess && want4) e = hipMemcpy(ctx->d_nodes4, h.nodes4, (size_t)h.n_nodes4 * sizeof(mrt::Dev4Node), hipMemcpyHostToDevice);
+	if (e == hipSuccess && h.nodes8) e = hipMemcpy(ctx->d_nodes8, h.nodes8, (size_t)h.n_nodes8 * sizeof(mrt::Dev8Node), hipMemcpyHostToDevice);
 	ctx->n_nodes4 = want4 ? h.n_nodes4 : 0;
+	ctx->n_nodes8 = h.nodes8 ? h.n_nodes8 : 0; ctx->stack8 = h.stack8;
 	for (int c = 0; c < 3; c++) { ctx->bounds_lo[c] = h.bounds_lo[c]; ctx->bounds_hi[c] = h.bounds_hi[c]; }
 	cleanup();
 	if (e != hipSuccess) { free_scene(ctx); std::snprintf(ctx->err, sizeof(ctx->err), "scene upload failed: %s", hipGetErrorString(e)); return MRT_ERR_HIP; }

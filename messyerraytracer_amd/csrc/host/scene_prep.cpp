@@ -18,6 +18,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <thread>
 #include <vector>
 #include "../mrt_internal.h"
 
@@ -235,6 +237,117 @@ int prepare_scene(const mrt_tri64 *tris, uint32_t n_tris, const mrt_bvh_node32 *
 		if (!out->nodes4) { std::free(hot); std::free(cold); std::free(out->nodes); out->nodes = nullptr; return fail(MRT_ERR_OOM, "upload_scene: out of host memory"); }
 		std::memcpy(out->nodes4, dev4.data(), dev4.size() * sizeof(Dev4Node));
 		out->stack4 = stack4;
+	}
+
+	// ---- 8-wide compressed collapse (built when out->want8): same greedy rule, up to 8 children,
+	//      child boxes quantised outwards to 8 bits on the node's own grid.  An optional layout: a box
+	//      that cannot be put on a grid (non-finite) only means the scene goes without it ----
+	bool ok8 = out->want8;
+	if (ok8) {
+		struct Child { float mn[3], mx[3]; uint32_t ref; };
+		auto area = [](const Child &c) {
+			const float e0 = c.mx[0] - c.mn[0], e1 = c.mx[1] - c.mn[1], e2 = c.mx[2] - c.mn[2];
+			return e0 * e1 + e1 * e2 + e2 * e0;
+		};
+		auto children_of = [&](uint32_t w, Child &l, Child &r) {
+			const DevNode &g = dev[w];
+			for (int c = 0; c < 3; c++) { l.mn[c] = g.lmin[c]; l.mx[c] = g.lmax[c]; r.mn[c] = g.rmin[c]; r.mx[c] = g.rmax[c]; }
+			l.ref = g.left_ref; r.ref = g.right_ref;
+		};
+		// phase 1 (sequential, cheap): topology -- which boxes and refs every 8-wide node holds
+		struct Kids { Child ch[8]; uint32_t n; };
+		struct Work { uint32_t w2, idx8, need; };
+		std::vector<Kids> kids;
+		std::vector<Work> work;
+		kids.emplace_back();
+		work.push_back({ 0u, 0u, 0u });
+		uint32_t stack8 = 1;
+		while (!work.empty()) {
+			const Work wk = work.back(); work.pop_back();
+			Kids k; k.n = 2;
+			children_of(wk.w2, k.ch[0], k.ch[1]);
+			while (k.n < 8) {
+				int best = -1; float best_a = -1.0f;
+				for (uint32_t i = 0; i < k.n; i++) if (k.ch[i].ref < kSentinel) { const float a = area(k.ch[i]); if (a > best_a) { best_a = a; best = (int)i; } }
+				if (best < 0) break;
+				Child l, r; children_of(k.ch[best].ref, l, r);
+				k.ch[best] = l; k.ch[k.n++] = r;
+			}
+			const uint32_t need = wk.need + (k.n - 1);
+			if (need + 1 > stack8) stack8 = need + 1;
+			for (uint32_t i = 0; i < k.n; i++) {
+				if (k.ch[i].ref < kSentinel) { // an inner child becomes an 8-wide node of its own
+					const uint32_t idx = (uint32_t)kids.size();
+					kids.emplace_back();
+					work.push_back({ k.ch[i].ref, idx, need });
+					k.ch[i].ref = idx;
+				}
+			}
+			kids[wk.idx8] = k;
+		}
+		// phase 2 (parallel): the grid of every node and the outward-rounded child boxes on it
+		std::vector<Dev8Node> dev8(kids.size());
+		std::atomic<bool> bad{false};
+		auto quantise = [&](size_t first, size_t last) {
+			for (size_t w = first; w < last; w++) {
+				const Kids &k = kids[w];
+				Dev8Node node;
+				std::memset(&node, 0, sizeof(node));
+				node.n_children = (uint8_t)k.n;
+				float scale[3] = { 1.0f, 1.0f, 1.0f };
+				for (int a = 0; a < 3; a++) {
+					float lo = k.ch[0].mn[a], hi = k.ch[0].mx[a];
+					for (uint32_t i = 1; i < k.n; i++) { lo = std::min(lo, k.ch[i].mn[a]); hi = std::max(hi, k.ch[i].mx[a]); }
+					node.org[a] = lo;
+					// smallest power-of-two step with (hi - lo) / step <= 254 (one step of headroom for the outward rounding)
+					int e = 1;
+					const double ext = (double)hi - (double)lo;
+					if (!(ext >= 0.0) || !std::isfinite(ext)) { bad = true; continue; } // NaN / infinite box
+					if (ext > 0.0) { e = (int)std::ceil(std::log2(ext / 254.0)) + 127; if (e < 1) e = 1; if (e > 254) e = 254; }
+					for (;;) { // guard against log2 rounding: make sure the extent fits
+						uint32_t bits = (uint32_t)e << 23; float s; std::memcpy(&s, &bits, 4);
+						if ((double)s * 254.0 >= ext || e >= 254) { scale[a] = s; break; }
+						e++;
+					}
+					node.exp[a] = (uint8_t)e;
+				}
+				for (uint32_t i = 0; i < 8; i++) {
+					if (i >= k.n) { node.ref[i] = kSentinel; continue; }
+					node.ref[i] = k.ch[i].ref;
+					for (int a = 0; a < 3 && !bad; a++) {
+						// outward rounding, verified on the value the kernel will decode: fmaf(q, scale, org)
+						int ql = (int)std::floor(((double)k.ch[i].mn[a] - (double)node.org[a]) / (double)scale[a]);
+						if (ql < 0) ql = 0; if (ql > 255) ql = 255;
+						while (ql > 0 && std::fmaf((float)ql, scale[a], node.org[a]) > k.ch[i].mn[a]) ql--;
+						int qh = (int)std::ceil(((double)k.ch[i].mx[a] - (double)node.org[a]) / (double)scale[a]);
+						if (qh < 0) qh = 0; if (qh > 255) qh = 255;
+						while (qh < 255 && std::fmaf((float)qh, scale[a], node.org[a]) < k.ch[i].mx[a]) qh++;
+						if (std::fmaf((float)ql, scale[a], node.org[a]) > k.ch[i].mn[a] || std::fmaf((float)qh, scale[a], node.org[a]) < k.ch[i].mx[a])
+							bad = true; // cannot happen for finite boxes (one step of headroom); never ship a box that does not contain its child
+						node.qlo[a][i] = (uint8_t)ql; node.qhi[a][i] = (uint8_t)qh;
+					}
+				}
+				dev8[w] = node;
+			}
+		};
+		unsigned n_thr = std::thread::hardware_concurrency();
+		if (n_thr > 16u) n_thr = 16u;
+		if (n_thr < 2u || kids.size() < 4096u) quantise(0, kids.size());
+		else {
+			std::vector<std::thread> pool;
+			for (unsigned t = 0; t < n_thr; t++)
+				pool.emplace_back(quantise, kids.size() * t / n_thr, kids.size() * (t + 1) / n_thr);
+			for (auto &th : pool) th.join();
+		}
+		ok8 = !bad;
+		if (ok8) {
+			out->nodes8 = (Dev8Node *)std::malloc(dev8.size() * sizeof(Dev8Node));
+			if (out->nodes8) {
+				out->n_nodes8 = (uint32_t)dev8.size();
+				std::memcpy(out->nodes8, dev8.data(), dev8.size() * sizeof(Dev8Node));
+				out->stack8 = stack8;
+			}
+		}
 	}
 	return MRT_OK;
 }

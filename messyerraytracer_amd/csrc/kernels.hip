@@ -589,14 +589,21 @@ hipError_t launch_trace_persistent(const TraceParams &p, unsigned long long *nex
 	PersistParams q;
 	q.next_ray = next_ray; q.overflow = overflow; q.overflow_stride = blocks * MRT_WG;
 	q.lds_depth = lds_depth; q.refill = refill; q.leaf_wait = leaf_wait ? leaf_wait : 1u;
+	// about 32 chunks per wave, between one wave's worth of rays and MRT_RAY_CHUNK
+	const uint64_t per_wave = p.count / ((uint64_t)blocks * (MRT_WG / MRT_WAVE)) / 32u;
+	q.chunk = per_wave >= MRT_RAY_CHUNK ? MRT_RAY_CHUNK : (per_wave <= MRT_WAVE ? MRT_WAVE : (uint32_t)(per_wave & ~63ull));
 	const size_t lds = (size_t)(MRT_WG / MRT_WAVE) * lds_depth * MRT_WAVE * sizeof(uint32_t);
+	const bool wide8 = p.kernel == MRT_KERNEL_LANE8_PERSISTENT && p.nodes8 != nullptr;
 	const bool wide4 = p.kernel == MRT_KERNEL_LANE4_PERSISTENT && p.nodes4 != nullptr;
-	if (wide4) {
-		if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true, true>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
-		else hipLaunchKernelGGL((trace_lane_persistent_kernel<false, true>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+	if (wide8) {
+		if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true, 8>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+		else hipLaunchKernelGGL((trace_lane_persistent_kernel<false, 8>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+	} else if (wide4) {
+		if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true, 4>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+		else hipLaunchKernelGGL((trace_lane_persistent_kernel<false, 4>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
 	} else {
-		if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true, false>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
-		else hipLaunchKernelGGL((trace_lane_persistent_kernel<false, false>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+		if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true, 2>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+		else hipLaunchKernelGGL((trace_lane_persistent_kernel<false, 2>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
 	}
 	return hipGetLastError();
 }

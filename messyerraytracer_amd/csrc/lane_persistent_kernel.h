@@ -26,9 +26,13 @@
 // node costs what a 2-wide node costs and a ray needs half as many).  Children are visited
 // nearest first (sorting network on packed distance|slot keys); the order never changes a
 // result.
+//
+// WIDTH 8: the 8-wide compressed collapse (Dev8Node: 8-bit child boxes on a per-node grid, decoded
+// with fma(q, step, origin) to boxes that contain the exact ones).  Still one line per step, and a
+// ray needs fewer again; the price is the decode arithmetic.
 #pragma once
 
-#define MRT_RAY_CHUNK 256u // rays a wave reserves per atomic on the global counter
+#define MRT_RAY_CHUNK 256u // most rays a wave reserves per atomic on a ray counter (PersistParams::chunk)
 
 struct PersistParams {
 	unsigned long long *next_ray; // 8 ray counters, one per region of the batch, 16 u64 apart (zeroed before the launch)
@@ -37,6 +41,8 @@ struct PersistParams {
 	uint32_t lds_depth;           // stack entries per lane kept in LDS
 	uint32_t refill;              // refill when at least this many lanes are idle
 	uint32_t leaf_wait;           // leave the node phase when this many lanes stand at a leaf
+	uint32_t chunk;               // rays a wave reserves at a time: MRT_RAY_CHUNK, less for batches that would
+	                              // otherwise give a wave only a few chunks (the last ones finish unevenly)
 };
 
 #ifdef MRT_PERSIST_WPE // experiment: ask the register allocator for at least this many waves per SIMD
@@ -45,7 +51,10 @@ struct PersistParams {
 #define MRT_PERSIST_ATTR
 #endif
 
-template <bool ANY_HIT, bool WIDE4>
+// byte k of a packed word as a float (v_cvt_f32_ubyteK)
+__device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }
+
+template <bool ANY_HIT, int WIDTH> // WIDTH: children per node step = 2 (DevNode), 4 (Dev4Node) or 8 (Dev8Node)
 __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent_kernel(const TraceParams p, const PersistParams q)
 {
 	extern __shared__ uint32_t lds_stack[];
@@ -55,6 +64,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 	const uint32_t lds_base = wave * (q.lds_depth * MRT_WAVE) + lane;
 	const float4 *nodes = reinterpret_cast<const float4 *>(p.nodes);
 	const float4 *nodes4 = reinterpret_cast<const float4 *>(p.nodes4);
+	const float4 *nodes8 = reinterpret_cast<const float4 *>(p.nodes8);
 	const float4 *hot = reinterpret_cast<const float4 *>(p.tri_hot);
 
 	// per-lane ray state
@@ -88,7 +98,16 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 		// ---- retire finished lanes, hand out new rays ----
 		const bool idle = cur == kSentinel;
 		if (idle && has_ray) {
-			finish_ray(p, ray_idx, r, best_t, best_u, best_v, best_slot);
+			// (not finish_ray(): its output-format branch around these loads measured 11 % slower here,
+			// 8.6 against 7.7 ms at C4; the lookups are unconditional in this kernel)
+			int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
+			if (best_slot != 0xFFFFFFFFu) {
+				prim = (int32_t)p.tri_hot[best_slot].id;
+				layers = p.tri_hot[best_slot].layers;
+				const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
+				nx = nn.x; ny = nn.y; nz = nn.z;
+			}
+			store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
 			has_ray = false;
 		}
 		const unsigned long long idle_mask = __ballot(idle);
@@ -107,11 +126,11 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 				while (regions_tried < 8u) {
 					const uint64_t lo = p.count * region / 8u, hi = p.count * (region + 1u) / 8u;
 					unsigned long long base = 0;
-					if (lane == (uint32_t)__builtin_ctzll(idle_mask)) base = atomicAdd(q.next_ray + region * 16u, (unsigned long long)MRT_RAY_CHUNK);
+					if (lane == (uint32_t)__builtin_ctzll(idle_mask)) base = atomicAdd(q.next_ray + region * 16u, (unsigned long long)q.chunk);
 					base = __shfl(base, __builtin_ctzll(idle_mask));
 					if (lo + base < hi) {
 						fresh_lo = lo + base;
-						fresh_hi = fresh_lo + MRT_RAY_CHUNK < hi ? fresh_lo + MRT_RAY_CHUNK : hi;
+						fresh_hi = fresh_lo + q.chunk < hi ? fresh_lo + q.chunk : hi;
 						break;
 					}
 					region = (region + 1u) & 7u; regions_tried++; // this region is handed out completely
@@ -150,7 +169,61 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 		for (;;) {
 			// NODE phase (wave-uniform loop, lanes at an inner node take the step)
 			while (__ballot(cur < kSentinel) != 0ull) {
-				if (WIDE4 && cur < kSentinel) { // 4-wide collapse: one 128-byte line per step
+				if (WIDTH == 8 && cur < kSentinel) { // 8-wide compressed node: one 128-byte line, 96 bytes read
+					const float4 *n = nodes8 + (size_t)cur * 8u;
+					const float4 h = n[0], qa = n[1], qb = n[2], qc = n[3], ra = n[4], rb = n[5];
+					const uint32_t meta = __float_as_uint(h.w);
+					const float sx = __uint_as_float((meta & 0xFFu) << 23), sy = __uint_as_float(((meta >> 8) & 0xFFu) << 23),
+							sz = __uint_as_float(((meta >> 16) & 0xFFu) << 23);
+					const uint32_t n_children = meta >> 24;
+					// [axis][child] bytes: qlo x = qa.xy, qlo y = qa.zw, qlo z = qb.xy, qhi x = qb.zw, qhi y = qc.xy, qhi z = qc.zw
+					const uint32_t lox[2] = { __float_as_uint(qa.x), __float_as_uint(qa.y) }, loy[2] = { __float_as_uint(qa.z), __float_as_uint(qa.w) };
+					const uint32_t loz[2] = { __float_as_uint(qb.x), __float_as_uint(qb.y) }, hix[2] = { __float_as_uint(qb.z), __float_as_uint(qb.w) };
+					const uint32_t hiy[2] = { __float_as_uint(qc.x), __float_as_uint(qc.y) }, hiz[2] = { __float_as_uint(qc.z), __float_as_uint(qc.w) };
+					const uint32_t ref[8] = { __float_as_uint(ra.x), __float_as_uint(ra.y), __float_as_uint(ra.z), __float_as_uint(ra.w),
+						__float_as_uint(rb.x), __float_as_uint(rb.y), __float_as_uint(rb.z), __float_as_uint(rb.w) };
+					const float lim = best_t;
+					uint32_t key[8];
+#pragma unroll
+					for (int c = 0; c < 8; c++) {
+						// decode first (the builder verified exactly these values), then the usual slab test
+						const float bx0 = fma_(ubyte_f(lox[c >> 2], c & 3), sx, h.x), bx1 = fma_(ubyte_f(hix[c >> 2], c & 3), sx, h.x);
+						const float by0 = fma_(ubyte_f(loy[c >> 2], c & 3), sy, h.y), by1 = fma_(ubyte_f(hiy[c >> 2], c & 3), sy, h.y);
+						const float bz0 = fma_(ubyte_f(loz[c >> 2], c & 3), sz, h.z), bz1 = fma_(ubyte_f(hiz[c >> 2], c & 3), sz, h.z);
+						const float x0 = fma_(bx0, ix, nrx), x1 = fma_(bx1, ix, nrx);
+						const float y0 = fma_(by0, iy, nry), y1 = fma_(by1, iy, nry);
+						const float z0 = fma_(bz0, iz, nrz), z1 = fma_(bz1, iz, nrz);
+						const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), r.t_min));
+						const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim));
+						key[c] = ((uint32_t)c < n_children && tnear <= tfar) ? ((__float_as_uint(tnear) & ~7u) | (uint32_t)c) : 0xFFFFFFFFu;
+					}
+					// front-to-back: 19-exchange sorting network on the packed keys, nearest child next, the
+					// others pushed farthest first (pushing them unsorted measured 3-6 % slower at C4)
+#define MRT_CS(a, b) { const uint32_t lo_ = min(key[a], key[b]), hi_ = max(key[a], key[b]); key[a] = lo_; key[b] = hi_; }
+					MRT_CS(0, 1) MRT_CS(2, 3) MRT_CS(4, 5) MRT_CS(6, 7) MRT_CS(0, 2) MRT_CS(1, 3) MRT_CS(4, 6) MRT_CS(5, 7)
+					MRT_CS(1, 2) MRT_CS(5, 6) MRT_CS(0, 4) MRT_CS(3, 7) MRT_CS(1, 5) MRT_CS(2, 6) MRT_CS(1, 4) MRT_CS(3, 6)
+					MRT_CS(2, 4) MRT_CS(3, 5) MRT_CS(3, 4)
+#undef MRT_CS
+					if (key[0] == 0xFFFFFFFFu) cur = pop();
+					else {
+						// ref of the slot in a key's low 3 bits: a select tree on scalars (an indexed array goes to scratch)
+						auto pick = [&](uint32_t k) {
+							const bool b0 = (k & 1u) != 0u, b1 = (k & 2u) != 0u, b2 = (k & 4u) != 0u;
+							const uint32_t p01 = b0 ? ref[1] : ref[0], p23 = b0 ? ref[3] : ref[2], p45 = b0 ? ref[5] : ref[4], p67 = b0 ? ref[7] : ref[6];
+							const uint32_t lo4 = b1 ? p23 : p01, hi4 = b1 ? p67 : p45;
+							return b2 ? hi4 : lo4;
+						};
+						if (key[7] != 0xFFFFFFFFu) push(pick(key[7]));
+						if (key[6] != 0xFFFFFFFFu) push(pick(key[6]));
+						if (key[5] != 0xFFFFFFFFu) push(pick(key[5]));
+						if (key[4] != 0xFFFFFFFFu) push(pick(key[4]));
+						if (key[3] != 0xFFFFFFFFu) push(pick(key[3]));
+						if (key[2] != 0xFFFFFFFFu) push(pick(key[2]));
+						if (key[1] != 0xFFFFFFFFu) push(pick(key[1]));
+						cur = pick(key[0]);
+					}
+				}
+				if (WIDTH == 4 && cur < kSentinel) { // 4-wide collapse: one 128-byte line per step
 					const float4 *n = nodes4 + (size_t)cur * 8u;
 					const float4 b0 = n[0], b1 = n[1], b2 = n[2], b3 = n[3], b4 = n[4], b5 = n[5], refs = n[6];
 					// child c box: min = (m[6c], m[6c+1], m[6c+2]), max = (m[6c+3], m[6c+4], m[6c+5])
@@ -184,7 +257,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 						cur = pick(key[0]);
 					}
 				}
-				if (!WIDE4 && cur < kSentinel) { // dual-AABB node: glsl:243-318
+				if (WIDTH == 2 && cur < kSentinel) { // dual-AABB node: glsl:243-318
 					const float4 *n = nodes + (size_t)cur * 4u;
 					const float4 a = n[0], b = n[1], c = n[2], d = n[3];
 					const float l0x = fma_(a.x, ix, nrx), l1x = fma_(b.x, ix, nrx);

@@ -53,6 +53,24 @@ struct alignas(16) Dev4Node {
 };
 static_assert(sizeof(Dev4Node) == 128, "Dev4Node must be 128 bytes");
 
+// 8-wide compressed node (Ylitie, Karras, Laine 2017, the layout idea of the
+// reference's cwbvh_traverse.comp.glsl, re-cut for one 128-byte cache line and explicit child refs):
+// child boxes are 8-bit coordinates on a per-node grid, lo = fma(q, 2^(exp-127), org) per axis.  The
+// builder rounds outwards and checks the DECODED value in float, so a decoded box contains the exact
+// one and the slab test on it (same formula as for exact boxes, monotone in the box coordinate)
+// passes whenever the test on the exact box does: the walk visits a superset of what the 2-wide walk
+// visits, and every triangle is still tested with the exact arithmetic.
+struct alignas(16) Dev8Node {
+	float org[3];
+	uint8_t exp[3];       // float exponent byte of the grid step per axis
+	uint8_t n_children;
+	uint8_t qlo[3][8];    // [axis][child]
+	uint8_t qhi[3][8];
+	uint32_t ref[8];      // DevNode encoding with wide8 indices; unused slots kSentinel
+	uint32_t pad[8];
+};
+static_assert(sizeof(Dev8Node) == 128, "Dev8Node must be 128 bytes");
+
 constexpr uint32_t kSentinel = 0x7FFFFFFFu;
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kLastInLeaf = 1u;
@@ -66,6 +84,7 @@ enum LaneMap : uint32_t { MAP_LINEAR = 0, MAP_TILE8X8 = 1, MAP_AUTO = 2 };
 struct TraceParams {
 	const DevNode *nodes;
 	const Dev4Node *nodes4;    // packet kernel, 4-wide layout (may be null)
+	const Dev8Node *nodes8;    // 8-wide compressed layout (may be null)
 	const TriHot *tri_hot;
 	const TriCold *tri_cold;
 	const void *rays;          // IN_RAY32 / IN_HOST60 (device)
@@ -94,6 +113,8 @@ struct DeviceSceneHost {
 	DevNode *nodes = nullptr; uint32_t n_nodes = 0;
 	Dev4Node *nodes4 = nullptr; uint32_t n_nodes4 = 0;
 	uint32_t stack4 = 0;        // per-wave stack entries the 4-wide walk can need
+	bool want8 = false;         // in: also build the 8-wide compressed collapse
+	Dev8Node *nodes8 = nullptr; uint32_t n_nodes8 = 0; uint32_t stack8 = 0;
 	float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0}; // scene AABB (sort key quantisation)
 	TriHot *hot = nullptr; TriCold *cold = nullptr; uint32_t n_tris = 0;
 	uint32_t depth = 0;         // max stack entries any traversal can need (incl. sentinel)

@@ -294,7 +294,8 @@ def test_counting_variant_matches_oracle_counters(built):
     c.close()
 
 
-@pytest.mark.parametrize("kernel", [capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT])
+@pytest.mark.parametrize("kernel", [capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
+                                    capi.KERNEL_LANE8_PERSISTENT])
 @pytest.mark.parametrize("lds_depth,refill,leaf_wait", [(4, 16, 0), (8, 1, 1), (16, 64, 64), (64, 16, 3)])
 def test_persistent_lane_kernel_spill_and_refill(built, lds_depth, refill, leaf_wait, kernel):
     """Resident waves pulling rays from a counter; stack entries beyond `lds_depth` spill to HBM.
@@ -354,7 +355,8 @@ def test_row_width_detection_for_coherent_batches(built):
 
 
 @pytest.mark.parametrize("kernel", [capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET4, capi.KERNEL_PACKET2,
-                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT])
+                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
+                                    capi.KERNEL_LANE8_PERSISTENT])
 def test_both_kernels_on_every_kind_of_batch(built, kernel):
     """Either kernel must give the oracle's answer for any batch, coherent or not:
     the kernel choice (MRT_KERNEL_AUTO) is a speed decision only."""
@@ -422,7 +424,8 @@ def test_async_flag_queues_casts_back_to_back(ctx, soup1k):
 
 
 @pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET4,
-                                    capi.KERNEL_PACKET2, capi.KERNEL_PACKET_ASM, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT])
+                                    capi.KERNEL_PACKET2, capi.KERNEL_PACKET_ASM, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
+                                    capi.KERNEL_LANE8_PERSISTENT])
 def test_hit_tokens_expand_to_identical_records(built, kernel):
     """MRT_FLAG_TOKEN_OUT + mrt_expand_tokens == the records of a plain cast, byte for byte
     (what lets the multi-GPU gather move 4 bytes per ray instead of 32)."""

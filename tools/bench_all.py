@@ -69,6 +69,10 @@ def incoherent_case(name, rounds, out):
                 ("wide4_24", dict(kernel=capi.KERNEL_LANE4_PERSISTENT, stack_override=24)),
                 ("wide4_32", dict(kernel=capi.KERNEL_LANE4_PERSISTENT, stack_override=32)),
                 ("wide4_16_r32", dict(kernel=capi.KERNEL_LANE4_PERSISTENT, refill=32)),
+                ("wide8", dict(kernel=capi.KERNEL_LANE8_PERSISTENT)),
+                ("wide8_l8", dict(kernel=capi.KERNEL_LANE8_PERSISTENT, leaf_wait=8)),
+                ("wide8_l32", dict(kernel=capi.KERNEL_LANE8_PERSISTENT, leaf_wait=32)),
+                ("wide8_s24", dict(kernel=capi.KERNEL_LANE8_PERSISTENT, stack_override=24)),
                 *[(f"p2_l{lw}_r{rf}", dict(kernel=capi.KERNEL_LANE_PERSISTENT, leaf_wait=lw, refill=rf))
                   for lw in (2, 4, 8, 16, 32, 64) for rf in (8, 16)],
                 *[(f"p4_l{lw}_r{rf}", dict(kernel=capi.KERNEL_LANE4_PERSISTENT, leaf_wait=lw, refill=rf))
