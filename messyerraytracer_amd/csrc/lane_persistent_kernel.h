@@ -183,18 +183,22 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 					const uint32_t ref[8] = { __float_as_uint(ra.x), __float_as_uint(ra.y), __float_as_uint(ra.z), __float_as_uint(ra.w),
 						__float_as_uint(rb.x), __float_as_uint(rb.y), __float_as_uint(rb.z), __float_as_uint(rb.w) };
 					const float lim = best_t;
+					// The near plane of an axis is the box's low or high coordinate by the sign of the ray's
+					// direction: choose between the packed words once (4 children per select) instead of a
+					// min and a max per child and axis.  Same values: fma is monotone in the box coordinate.
+					const bool ngx = ix < 0.0f, ngy = iy < 0.0f, ngz = iz < 0.0f;
+					const uint32_t nrw_x[2] = { ngx ? hix[0] : lox[0], ngx ? hix[1] : lox[1] }, far_x[2] = { ngx ? lox[0] : hix[0], ngx ? lox[1] : hix[1] };
+					const uint32_t nrw_y[2] = { ngy ? hiy[0] : loy[0], ngy ? hiy[1] : loy[1] }, far_y[2] = { ngy ? loy[0] : hiy[0], ngy ? loy[1] : hiy[1] };
+					const uint32_t nrw_z[2] = { ngz ? hiz[0] : loz[0], ngz ? hiz[1] : loz[1] }, far_z[2] = { ngz ? loz[0] : hiz[0], ngz ? loz[1] : hiz[1] };
 					uint32_t key[8];
 #pragma unroll
 					for (int c = 0; c < 8; c++) {
-						// decode first (the builder verified exactly these values), then the usual slab test
-						const float bx0 = fma_(ubyte_f(lox[c >> 2], c & 3), sx, h.x), bx1 = fma_(ubyte_f(hix[c >> 2], c & 3), sx, h.x);
-						const float by0 = fma_(ubyte_f(loy[c >> 2], c & 3), sy, h.y), by1 = fma_(ubyte_f(hiy[c >> 2], c & 3), sy, h.y);
-						const float bz0 = fma_(ubyte_f(loz[c >> 2], c & 3), sz, h.z), bz1 = fma_(ubyte_f(hiz[c >> 2], c & 3), sz, h.z);
-						const float x0 = fma_(bx0, ix, nrx), x1 = fma_(bx1, ix, nrx);
-						const float y0 = fma_(by0, iy, nry), y1 = fma_(by1, iy, nry);
-						const float z0 = fma_(bz0, iz, nrz), z1 = fma_(bz1, iz, nrz);
-						const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), r.t_min));
-						const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), lim));
+						// decode first (the builder verified exactly these values), then the usual slab arithmetic
+						const float tnx = fma_(fma_(ubyte_f(nrw_x[c >> 2], c & 3), sx, h.x), ix, nrx), tfx = fma_(fma_(ubyte_f(far_x[c >> 2], c & 3), sx, h.x), ix, nrx);
+						const float tny = fma_(fma_(ubyte_f(nrw_y[c >> 2], c & 3), sy, h.y), iy, nry), tfy = fma_(fma_(ubyte_f(far_y[c >> 2], c & 3), sy, h.y), iy, nry);
+						const float tnz = fma_(fma_(ubyte_f(nrw_z[c >> 2], c & 3), sz, h.z), iz, nrz), tfz = fma_(fma_(ubyte_f(far_z[c >> 2], c & 3), sz, h.z), iz, nrz);
+						const float tnear = fmaxf(fmaxf(tnx, tny), fmaxf(tnz, r.t_min));
+						const float tfar = fminf(fminf(tfx, tfy), fminf(tfz, lim));
 						key[c] = ((uint32_t)c < n_children && tnear <= tfar) ? ((__float_as_uint(tnear) & ~7u) | (uint32_t)c) : 0xFFFFFFFFu;
 					}
 					// front-to-back: 19-exchange sorting network on the packed keys, nearest child next, the

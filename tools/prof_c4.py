@@ -10,7 +10,7 @@ from messyerraytracer_amd import capi, synth  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 kernel = {"lane": capi.KERNEL_LANE, "persistent": capi.KERNEL_LANE_PERSISTENT,
-          "wide4": capi.KERNEL_LANE4_PERSISTENT}[sys.argv[2] if len(sys.argv) > 2 else "persistent"]
+          "wide4": capi.KERNEL_LANE4_PERSISTENT, "wide8": capi.KERNEL_LANE8_PERSISTENT}[sys.argv[2] if len(sys.argv) > 2 else "persistent"]
 sort = len(sys.argv) > 3 and sys.argv[3] == "1"
 cfg = synth.CONFIGS["C4"]
 scene = capi.Scene(synth.scene_vertices(cfg))
