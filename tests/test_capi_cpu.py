@@ -110,13 +110,13 @@ def test_triangles_and_camera_equal_oracle(built):
 
 def test_product_does_not_reference_the_oracle():
     """The product path may not import, link or call anything under oracle/."""
-    pkg = os.path.join(ROOT, "messyerraytracer_amd")
-    for dirpath, _, files in os.walk(pkg):
-        for fn in files:
-            if fn.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
-                text = open(os.path.join(dirpath, fn), errors="ignore").read()
-                assert "pyoracle" not in text and "liboracle" not in text and "mrt_oracle.h" not in text \
-                    and "libmrt_ref" not in text, f"{fn} references the oracle"
+    for top in ("messyerraytracer_amd", "tools", "include"):  # the product, its headers and the measuring tools
+        for dirpath, _, files in os.walk(os.path.join(ROOT, top)):
+            for fn in files:
+                if fn.endswith((".py", ".hip", ".cpp", ".hpp", ".h", ".sh")):
+                    text = open(os.path.join(dirpath, fn), errors="ignore").read()
+                    assert "pyoracle" not in text and "liboracle" not in text and "mrt_oracle.h" not in text \
+                        and "libmrt_ref" not in text, f"{fn} references the oracle"
     import subprocess
     out = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "oracle" not in out
