@@ -178,11 +178,10 @@ enum {
 	MRT_KERNEL_PACKET_ASM = 5, /* packet walk with the hand-written gfx950 node loop (default for coherent batches) */
 	MRT_KERNEL_LANE_PERSISTENT = 6, /* lane kernel with resident waves pulling rays from a counter, short LDS
 	                                  stack + HBM spill, node / leaf phases                                */
-	MRT_KERNEL_LANE4_PERSISTENT = 7, /* the same over the 4-wide collapse of the BVH, one 128-byte line per step
-	                                  (default for large incoherent batches)                               */
+	MRT_KERNEL_LANE4_PERSISTENT = 7, /* the same over the 4-wide collapse of the BVH, one 128-byte line per step */
 	MRT_KERNEL_LANE8_PERSISTENT = 8 /* the same over an 8-wide collapse with 8-bit child boxes on a per-node grid
 	                                  (compressed wide BVH, cf. the reference's cwbvh_traverse.comp.glsl), one
-	                                  128-byte line per step; host-built scenes only                      */
+	                                  128-byte line per step (default for large incoherent batches)       */
 };
 
 typedef struct mrt_options {

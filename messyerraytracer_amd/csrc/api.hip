@@ -541,12 +541,14 @@ int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	mrt::DeviceBuildResult b;
 	const bool want4 = ctx->opts.kernel == MRT_KERNEL_PACKET4 || ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
 			ctx->opts.kernel == MRT_KERNEL_AUTO;
-	rc = mrt::device_build_lbvh(d_tris, n_tris, want4, (void *)ctx->stream, &b, ctx->err, sizeof(ctx->err));
+	const bool want8 = ctx->opts.kernel == MRT_KERNEL_LANE8_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_AUTO;
+	rc = mrt::device_build_lbvh(d_tris, n_tris, want4, want8, (void *)ctx->stream, &b, ctx->err, sizeof(ctx->err));
 	if (staged) (void)hipFree(staged);
 	if (rc) return rc;
 	if (b.depth > 64) { // the packet kernels keep 64 stack entries per wave
 		(void)hipFree(b.nodes); (void)hipFree(b.hot); (void)hipFree(b.cold);
 		if (b.nodes4) (void)hipFree(b.nodes4);
+		if (b.nodes8) (void)hipFree(b.nodes8);
 		return fail(ctx, MRT_ERR_UNSUPPORTED, "device-built BVH deeper than the 64-entry traversal stack: build on the host");
 	}
 	HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
@@ -556,6 +558,7 @@ int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	free_scene(ctx);
 	ctx->d_nodes = b.nodes; ctx->d_hot = b.hot; ctx->d_cold = b.cold;
 	ctx->d_nodes4 = b.nodes4; ctx->n_nodes4 = b.nodes4 ? b.n_nodes : 0; ctx->stack4 = b.stack4;
+	ctx->d_nodes8 = b.nodes8; ctx->n_nodes8 = b.nodes8 ? b.n_nodes : 0; ctx->stack8 = b.stack8;
 	ctx->n_nodes = b.n_nodes; ctx->n_tris = b.n_tris; ctx->depth = b.depth;
 	for (int c = 0; c < 3; c++) { ctx->bounds_lo[c] = b.bounds_lo[c]; ctx->bounds_hi[c] = b.bounds_hi[c]; }
 	ctx->stack_depth = ((b.depth + 7u) / 8u) * 8u;

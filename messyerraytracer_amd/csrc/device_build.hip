@@ -256,6 +256,74 @@ __global__ __launch_bounds__(LBVH_WG) void lbvh_collapse4_kernel(const DevNode *
 	nodes4[b] = out;
 }
 
+// 5c. 8-wide compressed collapse (Dev8Node), same scheme as 5b: every binary node gets the 8-wide
+//     node it would be the root of, at its own index.  Quantisation exactly as on the host
+//     (scene_prep.cpp): power-of-two grid step with one step of headroom, outward rounding, and every
+//     quantised coordinate checked on the value the trace kernel will decode, fmaf(q, step, origin).
+//     A box that cannot be put on a grid (non-finite) raises *bad: the scene then goes without this layout.
+__global__ __launch_bounds__(LBVH_WG) void lbvh_collapse8_kernel(const DevNode *nodes, uint32_t n_nodes, Dev8Node *nodes8, uint32_t *bad)
+{
+	const uint32_t b = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (b >= n_nodes) return;
+	float box[8][6]; uint32_t ref[8]; uint32_t n = 2;
+	auto take = [&](const DevNode &g, uint32_t at_l, uint32_t at_r) {
+		for (int k = 0; k < 3; k++) {
+			box[at_l][k] = g.lmin[k]; box[at_l][3 + k] = g.lmax[k];
+			box[at_r][k] = g.rmin[k]; box[at_r][3 + k] = g.rmax[k];
+		}
+		ref[at_l] = g.left_ref; ref[at_r] = g.right_ref;
+	};
+	take(nodes[b], 0, 1);
+	while (n < 8) {
+		int best = -1; float best_a = -1.0f;
+		for (uint32_t i = 0; i < n; i++) {
+			if (ref[i] >= kSentinel) continue; // a leaf
+			const float e0 = box[i][3] - box[i][0], e1 = box[i][4] - box[i][1], e2 = box[i][5] - box[i][2];
+			const float a = e0 * e1 + e1 * e2 + e2 * e0;
+			if (a > best_a) { best_a = a; best = (int)i; }
+		}
+		if (best < 0) break;
+		take(nodes[ref[best]], (uint32_t)best, n);
+		n++;
+	}
+	Dev8Node out;
+	memset(&out, 0, sizeof(out));
+	out.n_children = (uint8_t)n;
+	float step[3] = { 1.0f, 1.0f, 1.0f };
+	bool ok = true;
+	for (int a = 0; a < 3; a++) {
+		float lo = box[0][a], hi = box[0][3 + a];
+		for (uint32_t i = 1; i < n; i++) { lo = fminf(lo, box[i][a]); hi = fmaxf(hi, box[i][3 + a]); }
+		out.org[a] = lo;
+		const double ext = (double)hi - (double)lo;
+		if (!(ext >= 0.0) || !(ext < 1.0e300)) { ok = false; continue; }
+		int e = 1;
+		if (ext > 0.0) { e = (int)ceil(log2(ext / 254.0)) + 127; if (e < 1) e = 1; if (e > 254) e = 254; }
+		for (;;) {
+			const float s = __uint_as_float((uint32_t)e << 23);
+			if ((double)s * 254.0 >= ext || e >= 254) { step[a] = s; break; }
+			e++;
+		}
+		out.exp[a] = (uint8_t)e;
+	}
+	for (uint32_t i = 0; i < 8; i++) {
+		if (i >= n) { out.ref[i] = kSentinel; continue; }
+		out.ref[i] = ref[i];
+		for (int a = 0; a < 3 && ok; a++) {
+			int ql = (int)floor(((double)box[i][a] - (double)out.org[a]) / (double)step[a]);
+			ql = ql < 0 ? 0 : (ql > 255 ? 255 : ql);
+			while (ql > 0 && __builtin_fmaf((float)ql, step[a], out.org[a]) > box[i][a]) ql--;
+			int qh = (int)ceil(((double)box[i][3 + a] - (double)out.org[a]) / (double)step[a]);
+			qh = qh < 0 ? 0 : (qh > 255 ? 255 : qh);
+			while (qh < 255 && __builtin_fmaf((float)qh, step[a], out.org[a]) < box[i][3 + a]) qh++;
+			if (__builtin_fmaf((float)ql, step[a], out.org[a]) > box[i][a] || __builtin_fmaf((float)qh, step[a], out.org[a]) < box[i][3 + a]) ok = false;
+			out.qlo[a][i] = (uint8_t)ql; out.qhi[a][i] = (uint8_t)qh;
+		}
+	}
+	if (!ok) atomicOr(bad, 1u);
+	nodes8[b] = out;
+}
+
 // 6. triangle rows in leaf order (sorted position = slot); every leaf holds one triangle
 __global__ __launch_bounds__(LBVH_WG) void lbvh_leaves_kernel(const mrt_tri64 *tris, uint32_t n, const uint32_t *sorted_tri, TriHot *hot, TriCold *cold)
 {
@@ -328,17 +396,18 @@ hipError_t launch_flatten_instances(const float *d_verts9, const mrt_instance *d
 		}                                                                                                \
 	} while (0)
 
-// Builds nodes / hot / cold (and nodes4 if want4; hipMalloc'ed, owned by the caller on success) for the
-// n >= 2 triangles at d_tris (device).  depth = stack entries a traversal can need (incl. the sentinel).
-int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, void *stream_, DeviceBuildResult *out, char *err, size_t err_len)
+// Builds nodes / hot / cold (and nodes4 / nodes8 if wanted; hipMalloc'ed, owned by the caller on success) for
+// the n >= 2 triangles at d_tris (device).  depth = stack entries a traversal can need (incl. the sentinel).
+int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want8, void *stream_, DeviceBuildResult *out, char *err, size_t err_len)
 {
 	hipStream_t stream = (hipStream_t)stream_;
 	void *tmp[16] = {}; int n_tmp = 0;
-	DevNode *nodes = nullptr; TriHot *hot = nullptr; TriCold *cold = nullptr; Dev4Node *nodes4 = nullptr;
+	DevNode *nodes = nullptr; TriHot *hot = nullptr; TriCold *cold = nullptr; Dev4Node *nodes4 = nullptr; Dev8Node *nodes8 = nullptr;
 	auto cleanup = [&] {
 		for (int i = 0; i < n_tmp; i++) if (tmp[i]) (void)hipFree(tmp[i]);
 		if (nodes) (void)hipFree(nodes);
 		if (nodes4) (void)hipFree(nodes4);
+		if (nodes8) (void)hipFree(nodes8);
 		if (hot) (void)hipFree(hot);
 		if (cold) (void)hipFree(cold);
 	};
@@ -360,7 +429,8 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, void *str
 	bool ok = boxes && scal && keys_a && keys_b && idx_a && idx_b && left && right && par_node && par_leaf && arrivals && node_depth && node_box;
 	ok = ok && hipMalloc(&nodes, (nn - 1) * sizeof(DevNode)) == hipSuccess && hipMalloc(&hot, nn * sizeof(TriHot) + 16) == hipSuccess &&
 			hipMalloc(&cold, nn * sizeof(TriCold)) == hipSuccess &&
-			(!want4 || hipMalloc(&nodes4, (nn - 1) * sizeof(Dev4Node)) == hipSuccess);
+			(!want4 || hipMalloc(&nodes4, (nn - 1) * sizeof(Dev4Node)) == hipSuccess) &&
+			(!want8 || hipMalloc(&nodes8, (nn - 1) * sizeof(Dev8Node)) == hipSuccess);
 	if (!ok) { std::snprintf(err, err_len, "device build: out of device memory"); cleanup(); return MRT_ERR_OOM; }
 
 	const uint32_t blocks = (uint32_t)((nn + LBVH_WG - 1) / LBVH_WG);
@@ -379,6 +449,7 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, void *str
 	hipLaunchKernelGGL(lbvh_fit_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, n, boxes, idx_b, left, right, par_node, par_leaf,
 			arrivals, node_box, node_depth, nodes, scal + 6);
 	if (want4) hipLaunchKernelGGL(lbvh_collapse4_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes4);
+	if (want8) hipLaunchKernelGGL(lbvh_collapse8_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes8, scal + 7);
 	hipLaunchKernelGGL(lbvh_leaves_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, d_tris, n, idx_b, hot, cold);
 	DB_TRY(hipGetLastError());
 	uint32_t h[8];
@@ -391,6 +462,8 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, void *str
 	out->depth = h[6] + 1u; // pending entries on the deepest path + the sentinel
 	// 4-wide walk: every 4-wide node on a path leaves at most 3 entries pending and descends at least one binary level
 	out->nodes4 = nodes4; out->stack4 = nodes4 ? 3u * h[6] + 1u : 0u;
+	if (nodes8 && h[7] != 0u) { (void)hipFree(nodes8); nodes8 = nullptr; } // a box that fits no grid: go without this layout
+	out->nodes8 = nodes8; out->stack8 = nodes8 ? 7u * h[6] + 1u : 0u;
 	for (int k = 0; k < 3; k++) { out->bounds_lo[k] = ord2f(h[k]); out->bounds_hi[k] = ord2f(h[3 + k]); }
 	return MRT_OK;
 }

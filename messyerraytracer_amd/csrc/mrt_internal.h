@@ -128,9 +128,10 @@ int prepare_scene(const mrt_tri64 *tris, uint32_t n_tris, const mrt_bvh_node32 *
 struct DeviceBuildResult {
 	DevNode *nodes = nullptr; TriHot *hot = nullptr; TriCold *cold = nullptr;
 	Dev4Node *nodes4 = nullptr;  // optional: one 4-wide node per binary node, at the binary node's index
-	uint32_t n_nodes = 0, n_tris = 0, depth = 0, stack4 = 0;
+	Dev8Node *nodes8 = nullptr;  // optional: likewise for the 8-wide compressed layout
+	uint32_t n_nodes = 0, n_tris = 0, depth = 0, stack4 = 0, stack8 = 0;
 	float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
 };
-int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, void *stream, DeviceBuildResult *out, char *err, size_t err_len);
+int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want8, void *stream, DeviceBuildResult *out, char *err, size_t err_len);
 
 } // namespace mrt
