@@ -246,7 +246,12 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
  * is walked) but walk more nodes per ray.  tris: host array, or device array with
  * MRT_BUILD_TRIS_ON_DEVICE.  mrt_stats.last_build_ms = device time of the build.
  * MRT_ERR_UNSUPPORTED if the tree comes out deeper than the traversal stack (build on the host). */
-enum { MRT_BUILD_TRIS_ON_DEVICE = 1u << 0 };
+enum {
+	MRT_BUILD_TRIS_ON_DEVICE = 1u << 0,
+	MRT_BUILD_SAFE_HANDOFF   = 1u << 1  /* the bottom-up pass hands boxes between threads with an acquire-release
+	                                       counter from the start (3x slower).  Every build verifies its tree
+	                                       afterwards and falls back to this form by itself if a hand-off was stale. */
+};
 int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris, uint32_t flags);
 
 /* A placed mesh: MeshBLAS + BLASInstance (src/accel/mesh_blas.h:86-138, blas_instance.h:47-107).

@@ -542,7 +542,8 @@ int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	const bool want4 = ctx->opts.kernel == MRT_KERNEL_PACKET4 || ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
 			ctx->opts.kernel == MRT_KERNEL_AUTO;
 	const bool want8 = ctx->opts.kernel == MRT_KERNEL_LANE8_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_AUTO;
-	rc = mrt::device_build_lbvh(d_tris, n_tris, want4, want8, (void *)ctx->stream, &b, ctx->err, sizeof(ctx->err));
+	rc = mrt::device_build_lbvh(d_tris, n_tris, want4, want8, (flags & MRT_BUILD_SAFE_HANDOFF) != 0, (void *)ctx->stream, &b,
+			ctx->err, sizeof(ctx->err));
 	if (staged) (void)hipFree(staged);
 	if (rc) return rc;
 	if (b.depth > 64) { // the packet kernels keep 64 stack entries per wave

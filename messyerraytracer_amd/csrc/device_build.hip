@@ -184,6 +184,10 @@ __device__ __forceinline__ void store_box_coherent(Box *dst, const Box &b)
 	__hip_atomic_store(p + 2, (unsigned long long)__float_as_uint(b.mx[1]) | ((unsigned long long)__float_as_uint(b.mx[2]) << 32), LBVH_RLX);
 }
 
+// SAFE: the counter is acquire-release on top of the write-through payload (3x slower; the retry of a
+// build whose verification pass found a stale hand-off -- never seen, but the fast form rests on
+// measured behaviour of the part, not on an architectural guarantee).
+template <bool SAFE>
 __global__ __launch_bounds__(LBVH_WG) void lbvh_fit_kernel(uint32_t n, const Box *tri_boxes, const uint32_t *sorted_tri,
 		const uint32_t *left, const uint32_t *right, const uint32_t *parent_of_node, const uint32_t *parent_of_leaf,
 		uint32_t *arrivals, Box *node_box, uint32_t *node_depth, DevNode *nodes, uint32_t *max_depth)
@@ -192,7 +196,8 @@ __global__ __launch_bounds__(LBVH_WG) void lbvh_fit_kernel(uint32_t n, const Box
 	if (leaf >= n) return;
 	uint32_t node = parent_of_leaf[leaf];
 	for (;;) {
-		const uint32_t before = __hip_atomic_fetch_add((lbvh_gu32 *)&arrivals[node], 1u, LBVH_RLX);
+		const uint32_t before = SAFE ? __hip_atomic_fetch_add((lbvh_gu32 *)&arrivals[node], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT)
+		                             : __hip_atomic_fetch_add((lbvh_gu32 *)&arrivals[node], 1u, LBVH_RLX);
 		if (before == 0u) return;
 		const uint32_t l = left[node], r = right[node];
 		const Box lb = (l & kLeafBit) ? tri_boxes[sorted_tri[l & 0x7FFFFFFFu]] : load_box_coherent(&node_box[l]);
@@ -215,6 +220,35 @@ __global__ __launch_bounds__(LBVH_WG) void lbvh_fit_kernel(uint32_t n, const Box
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the box and depth are out before the parent's counter moves
 		node = parent_of_node[node];
 	}
+}
+
+// 5a. Verification, after the kernel boundary (plain loads are coherent now): every box a node row holds
+//     for a child must be what that child's own row (or the leaf's triangle box) says, and depths must
+//     add up.  A hand-off that delivered a stale box or depth in the fit shows here as a mismatch.
+__global__ __launch_bounds__(LBVH_WG) void lbvh_verify_kernel(const DevNode *nodes, uint32_t n_nodes, const Box *tri_boxes,
+		const uint32_t *sorted_tri, const uint32_t *node_depth, const uint32_t *max_depth, uint32_t *bad)
+{
+	const uint32_t b = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (b >= n_nodes) return;
+	const DevNode g = nodes[b];
+	bool ok = true;
+	uint32_t deepest = 0u;
+	for (int side = 0; side < 2; side++) {
+		const uint32_t ref = side ? g.right_ref : g.left_ref;
+		const float *mn = side ? g.rmin : g.lmin, *mx = side ? g.rmax : g.lmax;
+		Box want;
+		if (ref & kLeafBit) want = tri_boxes[sorted_tri[ref & 0x7FFFFFFFu]];
+		else {
+			const DevNode c = nodes[ref];
+			for (int k = 0; k < 3; k++) { want.mn[k] = fminf(c.lmin[k], c.rmin[k]); want.mx[k] = fmaxf(c.lmax[k], c.rmax[k]); }
+			const uint32_t d = node_depth[ref];
+			deepest = d > deepest ? d : deepest;
+		}
+		for (int k = 0; k < 3; k++)
+			ok = ok && __float_as_uint(mn[k]) == __float_as_uint(want.mn[k]) && __float_as_uint(mx[k]) == __float_as_uint(want.mx[k]);
+	}
+	const uint32_t mine = b == 0u ? *max_depth : node_depth[b];
+	if (!ok || mine != deepest + 1u) atomicAdd(bad, 1u);
 }
 
 // 5b. 4-wide collapse for the incoherent-ray kernel (one 128-byte line per step): the rule of
@@ -398,7 +432,7 @@ hipError_t launch_flatten_instances(const float *d_verts9, const mrt_instance *d
 
 // Builds nodes / hot / cold (and nodes4 / nodes8 if wanted; hipMalloc'ed, owned by the caller on success) for
 // the n >= 2 triangles at d_tris (device).  depth = stack entries a traversal can need (incl. the sentinel).
-int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want8, void *stream_, DeviceBuildResult *out, char *err, size_t err_len)
+int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want8, bool safe_handoff, void *stream_, DeviceBuildResult *out, char *err, size_t err_len)
 {
 	hipStream_t stream = (hipStream_t)stream_;
 	void *tmp[16] = {}; int n_tmp = 0;
@@ -419,7 +453,7 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 	};
 	const size_t nn = n;
 	Box *boxes = (Box *)alloc(nn * sizeof(Box));
-	uint32_t *scal = (uint32_t *)alloc(8 * sizeof(uint32_t)); // bounds[6], max_depth, pad
+	uint32_t *scal = (uint32_t *)alloc(16 * sizeof(uint32_t)); // bounds[6], max_depth, 8-wide "bad" flag, verification failures
 	uint64_t *keys_a = (uint64_t *)alloc(nn * 8), *keys_b = (uint64_t *)alloc(nn * 8);
 	uint32_t *idx_a = (uint32_t *)alloc(nn * 4), *idx_b = (uint32_t *)alloc(nn * 4);
 	uint32_t *left = (uint32_t *)alloc(nn * 4), *right = (uint32_t *)alloc(nn * 4);
@@ -434,7 +468,7 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 	if (!ok) { std::snprintf(err, err_len, "device build: out of device memory"); cleanup(); return MRT_ERR_OOM; }
 
 	const uint32_t blocks = (uint32_t)((nn + LBVH_WG - 1) / LBVH_WG);
-	const uint32_t init[8] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u };
+	const uint32_t init[16] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
 	DB_TRY(hipMemcpyAsync(scal, init, sizeof(init), hipMemcpyHostToDevice, stream));
 	DB_TRY(hipMemsetAsync(arrivals, 0, nn * 4, stream));
 	hipLaunchKernelGGL(lbvh_bounds_kernel, dim3(blocks < LBVH_BOUNDS_BLOCKS ? blocks : LBVH_BOUNDS_BLOCKS), dim3(LBVH_WG), 0, stream,
@@ -446,15 +480,28 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 	if (!sort_tmp) { std::snprintf(err, err_len, "device build: out of device memory"); cleanup(); return MRT_ERR_OOM; }
 	DB_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys_a, keys_b, idx_a, idx_b, nn, 0, 63, stream));
 	hipLaunchKernelGGL(lbvh_hierarchy_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, keys_b, n, left, right, par_node, par_leaf);
-	hipLaunchKernelGGL(lbvh_fit_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, n, boxes, idx_b, left, right, par_node, par_leaf,
-			arrivals, node_box, node_depth, nodes, scal + 6);
-	if (want4) hipLaunchKernelGGL(lbvh_collapse4_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes4);
-	if (want8) hipLaunchKernelGGL(lbvh_collapse8_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes8, scal + 7);
 	hipLaunchKernelGGL(lbvh_leaves_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, d_tris, n, idx_b, hot, cold);
-	DB_TRY(hipGetLastError());
-	uint32_t h[8];
-	DB_TRY(hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, stream));
-	DB_TRY(hipStreamSynchronize(stream));
+	uint32_t h[16];
+	// attempt 0: write-through hand-off; attempt 1: acquire-release hand-off, if the verification failed (or asked for)
+	for (int attempt = safe_handoff ? 1 : 0;; attempt++) {
+		if (attempt == 0)
+			hipLaunchKernelGGL(lbvh_fit_kernel<false>, dim3(blocks), dim3(LBVH_WG), 0, stream, n, boxes, idx_b, left, right, par_node, par_leaf,
+					arrivals, node_box, node_depth, nodes, scal + 6);
+		else {
+			DB_TRY(hipMemsetAsync(arrivals, 0, nn * 4, stream));
+			DB_TRY(hipMemsetAsync(scal + 6, 0, 3 * sizeof(uint32_t), stream));
+			hipLaunchKernelGGL(lbvh_fit_kernel<true>, dim3(blocks), dim3(LBVH_WG), 0, stream, n, boxes, idx_b, left, right, par_node, par_leaf,
+					arrivals, node_box, node_depth, nodes, scal + 6);
+		}
+		hipLaunchKernelGGL(lbvh_verify_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, boxes, idx_b, node_depth, scal + 6, scal + 8);
+		if (want4) hipLaunchKernelGGL(lbvh_collapse4_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes4);
+		if (want8) hipLaunchKernelGGL(lbvh_collapse8_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes8, scal + 7);
+		DB_TRY(hipGetLastError());
+		DB_TRY(hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, stream));
+		DB_TRY(hipStreamSynchronize(stream));
+		if (h[8] == 0u) break;
+		if (attempt >= 1) { std::snprintf(err, err_len, "device build: the tree failed its verification pass (%u nodes)", h[8]); cleanup(); return MRT_ERR_HIP; }
+	}
 	for (int i = 0; i < n_tmp; i++) (void)hipFree(tmp[i]);
 	n_tmp = 0;
 	out->nodes = nodes; out->hot = hot; out->cold = cold;

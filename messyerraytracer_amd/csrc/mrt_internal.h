@@ -132,6 +132,7 @@ struct DeviceBuildResult {
 	uint32_t n_nodes = 0, n_tris = 0, depth = 0, stack4 = 0, stack8 = 0;
 	float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
 };
-int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want8, void *stream, DeviceBuildResult *out, char *err, size_t err_len);
+int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want8, bool safe_handoff, void *stream,
+		DeviceBuildResult *out, char *err, size_t err_len);
 
 } // namespace mrt

@@ -90,6 +90,9 @@ def test_device_resident_triangles_and_rebuild(built):
     _check(c, po.OracleScene(v), "host after device")
     c.build_scene_device(capi.make_triangles(v))
     _check(c, po.OracleScene(v), "device after host")
+    # the acquire-release hand-off (what a build falls back to if its verification pass fails)
+    c.build_scene_device(capi.make_triangles(v), safe_handoff=True)
+    _check(c, po.OracleScene(v), "safe hand-off")
     with pytest.raises(capi.MrtError):
         c.build_scene_device(np.zeros(0, dtype=T.TRI64))
     c.close()
