@@ -200,7 +200,7 @@ typedef struct mrt_options {
 	                             direction-only key (ray_sort.h:64-76); the order never changes results */
 	uint32_t refill;          /* persistent lane kernel: refill a wave when this many lanes are idle (default 16) */
 	uint32_t leaf_wait;       /* persistent lane kernel: leave the node phase when this many lanes stand at a
-	                             leaf (default 16; 64 = classic while-while)                           */
+	                             leaf (default 8 for the 8-wide walk, else 16; 64 = classic while-while) */
 	uint32_t reserved[4];
 } mrt_options;
 

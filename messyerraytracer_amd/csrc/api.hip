@@ -184,11 +184,11 @@ int device_sort(mrt_ctx *ctx, const void *d_rays, uint32_t in_fmt, uint64_t coun
 int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit, bool persistent)
 {
 	int rc;
-	// the 4-wide walk (default for large incoherent batches: 7.8 ms against 11.0 ms at C4) exists in
-	// persistent form only
+	// The wide walks exist in persistent form only.  For large incoherent batches MRT_KERNEL_AUTO takes the
+	// 8-wide compressed layout when the scene has it (6.1 ms at C4), else the 4-wide one (7.7 ms), else the
+	// 2-wide persistent kernel (11.0 ms).
 	const bool wide4 = ctx->d_nodes4 != nullptr && (ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
 			(ctx->opts.kernel == MRT_KERNEL_AUTO && persistent));
-	// the 8-wide compressed walk where the scene has that layout (host-built scenes): 6.5 against 7.7 ms at C4
 	const bool wide8 = ctx->d_nodes8 != nullptr && (ctx->opts.kernel == MRT_KERNEL_LANE8_PERSISTENT ||
 			(ctx->opts.kernel == MRT_KERNEL_AUTO && persistent));
 	if ((wide4 || wide8) && !ctx->opts.count_visits) persistent = true;
