@@ -605,3 +605,26 @@ void orc_unpack_hits(const orc_hit32 *hits, const orc_host_ray60 *rays, uint64_t
 		}
 	}
 }
+
+/* ---- scene flatten: RayTracerServer::_rebuild_scene, src/godot/raytracer_server.cpp:700-711 ----
+ * For every instance in order, for every triangle of its mesh: a, b, c = inst.transform.xform(v0, v1, v2),
+ * Triangle(a, b, c, tri_offset++, layer mask of the mesh).  Transform3D::xform(v) is
+ * (basis.rows[k].dot(v) + origin[k]) for k = 0..2 and Vector3::dot is x*x' + y*y' + z*z' summed left to
+ * right (godot-cpp is not vendored in the reference tree; the reference's own a*b+c style, no fma). */
+void orc_flatten_instances(const float *verts9, const orc_instance *inst, uint32_t n_inst, orc_tri64 *out)
+{
+	uint32_t tri_offset = 0;
+	for (uint32_t i = 0; i < n_inst; i++) {
+		const orc_instance *in = &inst[i];
+		for (uint32_t k = 0; k < in->n_tris; k++) {
+			const float *src = verts9 + 9 * (size_t)(in->first_tri + k);
+			float w[9];
+			for (int v = 0; v < 3; v++)
+				for (int r = 0; r < 3; r++)
+					w[3 * v + r] = ((in->basis[3 * r] * src[3 * v] + in->basis[3 * r + 1] * src[3 * v + 1]) +
+							in->basis[3 * r + 2] * src[3 * v + 2]) + in->origin[r];
+			const uint32_t id = tri_offset++;
+			orc_make_triangles(w, &id, &in->layers, 1, &out[id]);
+		}
+	}
+}

@@ -37,6 +37,10 @@ typedef struct {
 
 /* src/core/triangle.h:41-51 */
 void orc_make_triangles(const float *verts9, const uint32_t *ids, const uint32_t *layers, uint32_t n, orc_tri64 *out);
+/* a placed mesh: MeshBLAS + BLASInstance (src/accel/mesh_blas.h:86-138, blas_instance.h:47-107) */
+typedef struct { uint32_t first_tri, n_tris, layers, reserved; float basis[9]; float origin[3]; } orc_instance;
+/* scene flatten of RayTracerServer::_rebuild_scene (src/godot/raytracer_server.cpp:700-711) */
+void orc_flatten_instances(const float *verts9, const orc_instance *inst, uint32_t n_inst, orc_tri64 *out);
 /* tiny_bvh.h:2261-2330 (PrepareBuild) + :2332-2466 (Build), single-threaded numbering */
 int orc_bvh2_build(const float *verts4, uint32_t n_tris, orc_node32 *nodes, uint32_t *prim_idx, uint32_t *used_nodes);
 /* tiny_bvh.h:1889-1897, :3698-3728 + depth */

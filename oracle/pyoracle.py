@@ -70,6 +70,17 @@ def make_triangles(verts9, ids=None, layers=None):
     return out
 
 
+def flatten_instances(verts9, instances):
+    """World-space triangles (TRI64) of placed meshes: raytracer_server.cpp:700-711 restated in mrt_oracle.c.
+    instances: structured array with the layout of orc_instance (64 bytes)."""
+    v = np.ascontiguousarray(verts9, dtype=np.float32).reshape(-1, 9)
+    inst = np.ascontiguousarray(instances)
+    assert inst.dtype.itemsize == 64
+    out = np.zeros(int(inst["n_tris"].sum()), dtype=TRI64)
+    lib().orc_flatten_instances(_p(v), _p(inst), C.c_uint32(inst.shape[0]), _p(out))
+    return out
+
+
 def verts4(verts9):
     v = np.ascontiguousarray(verts9, dtype=np.float32).reshape(-1, 3)
     out = np.zeros((v.shape[0], 4), dtype=np.float32)

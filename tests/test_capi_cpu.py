@@ -127,5 +127,14 @@ def test_instances_flatten_to_the_multi_mesh_scene():
     raytracer_server.cpp:700-711) reproduce the C5 generator bit for bit."""
     from messyerraytracer_amd import synth
     local, inst = synth.multi_mesh_instances(5, 300, 0.05, 11)
-    assert synth.flatten_instances(local, inst).tobytes() == synth.multi_mesh(5, 300, 0.05, 11)[0].tobytes()
+    world = synth.flatten_instances(local, inst)
+    assert world.tobytes() == synth.multi_mesh(5, 300, 0.05, 11)[0].tobytes()
     assert inst["n_tris"].sum() == 1500 and inst.dtype.itemsize == 64
+    # the oracle's restatement of the flatten + Triangle ctor gives the triangles of the flattened vertices
+    from oracle import pyoracle as po
+    inst["layers"] = [1, 2, 4, 8, 16]
+    flat = po.flatten_instances(local, inst)
+    want = po.make_triangles(world, np.arange(1500, dtype=np.uint32), np.repeat(inst["layers"], inst["n_tris"]).astype(np.uint32))
+    assert flat.tobytes() == want.tobytes()
+    assert capi.make_triangles(world, np.arange(1500, dtype=np.uint32),
+                               np.repeat(inst["layers"], inst["n_tris"]).astype(np.uint32)).tobytes() == want.tobytes()

@@ -155,7 +155,8 @@ def test_instances_flattened_and_built_on_the_device(built):
     assert n == 10 * 2000
     ids = np.arange(n, dtype=np.uint32)
     layers = np.repeat(inst["layers"], inst["n_tris"]).astype(np.uint32)
-    want = capi.make_triangles(world, ids, layers)
+    want = po.flatten_instances(local, inst)            # oracle: raytracer_server.cpp:700-711 + Triangle ctor
+    assert want.tobytes() == capi.make_triangles(world, ids, layers).tobytes()
     c = capi.Context(0)
     d_out = c.device_alloc(n * 64)
     c.flatten_instances(local, inst, d_out)
