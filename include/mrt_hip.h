@@ -173,8 +173,8 @@ enum {
 	MRT_KERNEL_AUTO = 0,
 	MRT_KERNEL_LANE = 1,    /* one lane = one ray, per-lane LDS stack, while-while loop         */
 	MRT_KERNEL_PACKET = 2,  /* one wave = one 64-ray packet, per-wave LDS stack, scalar fetches */
-	MRT_KERNEL_PACKET4 = 3, /* packet walk over the 4-wide collapse of the same BVH2 (128-B fetches) */
-	MRT_KERNEL_PACKET2 = 4, /* two packets per wave advanced in lockstep (two fetch chains in flight)  */
+	MRT_KERNEL_PACKET4 = 3, /* retired (a packet walk over the 4-wide collapse): runs MRT_KERNEL_PACKET */
+	MRT_KERNEL_PACKET2 = 4, /* retired (two packets per wave in lockstep): runs MRT_KERNEL_PACKET      */
 	MRT_KERNEL_PACKET_ASM = 5, /* packet walk with the hand-written gfx950 node loop (default for coherent batches) */
 	MRT_KERNEL_LANE_PERSISTENT = 6, /* lane kernel with resident waves pulling rays from a counter, short LDS
 	                                  stack + HBM spill, node / leaf phases                                */

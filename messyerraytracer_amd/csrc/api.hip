@@ -50,6 +50,7 @@ struct mrt_ctx {
 	mrt::DevNode *d_nodes = nullptr; mrt::TriHot *d_hot = nullptr; mrt::TriCold *d_cold = nullptr;
 	mrt::Dev4Node *d_nodes4 = nullptr; uint32_t n_nodes4 = 0;
 	mrt::Dev8Node *d_nodes8 = nullptr; uint32_t n_nodes8 = 0, stack8 = 0;
+	float *d_leaf_box = nullptr; // exact leaf boxes that go with d_nodes8
 	float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
 	uint32_t n_nodes = 0, n_tris = 0, depth = 0, stack_depth = 0, stack4 = 0;
 	bool scene = false;
@@ -106,6 +107,8 @@ void free_scene(mrt_ctx *ctx)
 	if (ctx->d_cold) (void)hipFree(ctx->d_cold);
 	if (ctx->d_nodes4) (void)hipFree(ctx->d_nodes4);
 	if (ctx->d_nodes8) (void)hipFree(ctx->d_nodes8);
+	if (ctx->d_leaf_box) (void)hipFree(ctx->d_leaf_box);
+	ctx->d_leaf_box = nullptr;
 	ctx->d_nodes = nullptr; ctx->d_hot = nullptr; ctx->d_cold = nullptr; ctx->d_nodes4 = nullptr; ctx->d_nodes8 = nullptr;
 	ctx->n_nodes8 = ctx->stack8 = 0;
 	ctx->scene = false; ctx->n_nodes = ctx->n_tris = 0;
@@ -129,7 +132,7 @@ uint32_t out_format(uint32_t flags, int mode)
 void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 {
 	std::memset(&p, 0, sizeof(p));
-	p.nodes = ctx->d_nodes; p.nodes4 = ctx->d_nodes4; p.nodes8 = ctx->d_nodes8; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold;
+	p.nodes = ctx->d_nodes; p.nodes4 = ctx->d_nodes4; p.nodes8 = ctx->d_nodes8; p.leaf_box = ctx->d_leaf_box; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold;
 	p.stack_depth = ctx->stack_depth; p.n_tris = ctx->n_tris;
 	if (ctx->opts.stack_override >= ctx->depth && ctx->opts.stack_override <= 64) p.stack_depth = ctx->opts.stack_override;
 	p.counters = ctx->d_counters;
@@ -143,11 +146,10 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 // primary-ray grids), one lane per ray for everything else (sorted / incoherent batches).
 uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent)
 {
-	// the 4-wide packet kernel keeps 128 stack entries per wave; a device-built tree only has a loose bound
-	if (ctx->opts.kernel == MRT_KERNEL_PACKET4 && (!ctx->d_nodes4 || ctx->stack4 > 128u)) return MRT_KERNEL_PACKET;
+	// the 4-wide and the dual packet walks are retired (slower than the plain packet loop, and not
+	// exact for rays that lie in a box face): their ids run the packet kernel
+	if (ctx->opts.kernel == MRT_KERNEL_PACKET4 || ctx->opts.kernel == MRT_KERNEL_PACKET2) return MRT_KERNEL_PACKET;
 	if (ctx->opts.kernel >= MRT_KERNEL_LANE && ctx->opts.kernel <= MRT_KERNEL_LANE8_PERSISTENT) return ctx->opts.kernel;
-	// (PACKET4 halves the fetch chain but measured 7 % slower at C3: the walk is bound by
-	// instruction issue, and ordering four children costs more scalar work than it saves)
 	// PACKET_ASM: same walk with the hand-written node loop (the compiler's loop is scalar-ALU bound)
 	return coherent ? MRT_KERNEL_PACKET_ASM : MRT_KERNEL_LANE;
 }
@@ -474,20 +476,20 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	h.want8 = ctx->opts.kernel == MRT_KERNEL_LANE8_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_AUTO;
 	rc = mrt::prepare_scene(tris, n_tris, nodes, used_nodes, prim_idx, &h, ctx->err, sizeof(ctx->err));
 	if (rc) return rc;
-	auto cleanup = [&] { std::free(h.nodes); std::free(h.nodes4); std::free(h.nodes8); std::free(h.hot); std::free(h.cold); };
+	auto cleanup = [&] { std::free(h.nodes); std::free(h.nodes4); std::free(h.nodes8); std::free(h.leaf_box); std::free(h.hot); std::free(h.cold); };
 	if (h.depth > 64 || h.stack4 > 128) { cleanup(); return fail(ctx, MRT_ERR_UNSUPPORTED, "BVH deeper than the 64-entry traversal stack"); }
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	free_scene(ctx);
 	hipError_t e;
 	// the 4-wide layout is resident only when a kernel that walks it is asked for
-	const bool want4 = ctx->opts.kernel == MRT_KERNEL_PACKET4 || ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
-			ctx->opts.kernel == MRT_KERNEL_AUTO;
+	const bool want4 = ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_AUTO;
 	if ((e = hipMalloc(&ctx->d_nodes, (size_t)h.n_nodes * sizeof(mrt::DevNode))) != hipSuccess ||
-			// +16 B: the dual-packet kernel fetches 64 B at a 48-B triangle (the tail is never used)
+			// +16 B of slack: a 64-B scalar fetch at the last 48-B triangle stays inside the allocation
 			(e = hipMalloc(&ctx->d_hot, (size_t)h.n_tris * sizeof(mrt::TriHot) + 16)) != hipSuccess ||
 			(e = hipMalloc(&ctx->d_cold, (size_t)h.n_tris * sizeof(mrt::TriCold))) != hipSuccess ||
 			(want4 && (e = hipMalloc(&ctx->d_nodes4, (size_t)h.n_nodes4 * sizeof(mrt::Dev4Node))) != hipSuccess) ||
-			(h.nodes8 && (e = hipMalloc(&ctx->d_nodes8, (size_t)h.n_nodes8 * sizeof(mrt::Dev8Node))) != hipSuccess)) {
+			(h.nodes8 && ((e = hipMalloc(&ctx->d_nodes8, (size_t)h.n_nodes8 * sizeof(mrt::Dev8Node))) != hipSuccess ||
+					(e = hipMalloc(&ctx->d_leaf_box, (size_t)h.n_tris * 32)) != hipSuccess))) {
 		cleanup(); free_scene(ctx);
 		return fail(ctx, MRT_ERR_OOM, "scene does not fit in device memory");
 	}
@@ -496,6 +498,7 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	if (e == hipSuccess) e = hipMemcpy(ctx->d_cold, h.cold, (size_t)h.n_tris * sizeof(mrt::TriCold), hipMemcpyHostToDevice);
 	if (e == hipSuccess && want4) e = hipMemcpy(ctx->d_nodes4, h.nodes4, (size_t)h.n_nodes4 * sizeof(mrt::Dev4Node), hipMemcpyHostToDevice);
 	if (e == hipSuccess && h.nodes8) e = hipMemcpy(ctx->d_nodes8, h.nodes8, (size_t)h.n_nodes8 * sizeof(mrt::Dev8Node), hipMemcpyHostToDevice);
+	if (e == hipSuccess && h.nodes8) e = hipMemcpy(ctx->d_leaf_box, h.leaf_box, (size_t)h.n_tris * 32, hipMemcpyHostToDevice);
 	ctx->n_nodes4 = want4 ? h.n_nodes4 : 0;
 	ctx->n_nodes8 = h.nodes8 ? h.n_nodes8 : 0; ctx->stack8 = h.stack8;
 	for (int c = 0; c < 3; c++) { ctx->bounds_lo[c] = h.bounds_lo[c]; ctx->bounds_hi[c] = h.bounds_hi[c]; }
@@ -539,8 +542,7 @@ int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 		d_tris = (const mrt_tri64 *)staged;
 	}
 	mrt::DeviceBuildResult b;
-	const bool want4 = ctx->opts.kernel == MRT_KERNEL_PACKET4 || ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
-			ctx->opts.kernel == MRT_KERNEL_AUTO;
+	const bool want4 = ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_AUTO;
 	const bool want8 = ctx->opts.kernel == MRT_KERNEL_LANE8_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_AUTO;
 	rc = mrt::device_build_lbvh(d_tris, n_tris, want4, want8, (flags & MRT_BUILD_SAFE_HANDOFF) != 0, (void *)ctx->stream, &b,
 			ctx->err, sizeof(ctx->err));
@@ -550,6 +552,7 @@ int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 		(void)hipFree(b.nodes); (void)hipFree(b.hot); (void)hipFree(b.cold);
 		if (b.nodes4) (void)hipFree(b.nodes4);
 		if (b.nodes8) (void)hipFree(b.nodes8);
+		if (b.leaf_box) (void)hipFree(b.leaf_box);
 		return fail(ctx, MRT_ERR_UNSUPPORTED, "device-built BVH deeper than the 64-entry traversal stack: build on the host");
 	}
 	HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
@@ -559,7 +562,7 @@ int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	free_scene(ctx);
 	ctx->d_nodes = b.nodes; ctx->d_hot = b.hot; ctx->d_cold = b.cold;
 	ctx->d_nodes4 = b.nodes4; ctx->n_nodes4 = b.nodes4 ? b.n_nodes : 0; ctx->stack4 = b.stack4;
-	ctx->d_nodes8 = b.nodes8; ctx->n_nodes8 = b.nodes8 ? b.n_nodes : 0; ctx->stack8 = b.stack8;
+	ctx->d_nodes8 = b.nodes8; ctx->d_leaf_box = b.leaf_box; ctx->n_nodes8 = b.nodes8 ? b.n_nodes : 0; ctx->stack8 = b.stack8;
 	ctx->n_nodes = b.n_nodes; ctx->n_tris = b.n_tris; ctx->depth = b.depth;
 	for (int c = 0; c < 3; c++) { ctx->bounds_lo[c] = b.bounds_lo[c]; ctx->bounds_hi[c] = b.bounds_hi[c]; }
 	ctx->stack_depth = ((b.depth + 7u) / 8u) * 8u;

@@ -295,7 +295,9 @@ __global__ __launch_bounds__(LBVH_WG) void lbvh_collapse4_kernel(const DevNode *
 //     (scene_prep.cpp): power-of-two grid step with one step of headroom, outward rounding, and every
 //     quantised coordinate checked on the value the trace kernel will decode, fmaf(q, step, origin).
 //     A box that cannot be put on a grid (non-finite) raises *bad: the scene then goes without this layout.
-__global__ __launch_bounds__(LBVH_WG) void lbvh_collapse8_kernel(const DevNode *nodes, uint32_t n_nodes, Dev8Node *nodes8, uint32_t *bad)
+//     Also writes the exact box of every leaf (leaf_box, 8 floats per slot; each leaf once, by its binary
+//     parent): the 8-wide walk checks a candidate hit against it (mrt_internal.h, Dev8Node).
+__global__ __launch_bounds__(LBVH_WG) void lbvh_collapse8_kernel(const DevNode *nodes, uint32_t n_nodes, Dev8Node *nodes8, float *leaf_box, uint32_t *bad)
 {
 	const uint32_t b = blockIdx.x * LBVH_WG + threadIdx.x;
 	if (b >= n_nodes) return;
@@ -308,6 +310,12 @@ __global__ __launch_bounds__(LBVH_WG) void lbvh_collapse8_kernel(const DevNode *
 		ref[at_l] = g.left_ref; ref[at_r] = g.right_ref;
 	};
 	take(nodes[b], 0, 1);
+	for (uint32_t i = 0; i < 2; i++)
+		if (ref[i] >= kLeafBit) {
+			float4 *lb = (float4 *)leaf_box + (size_t)(ref[i] & 0x7FFFFFFFu) * 2u;
+			lb[0] = make_float4(box[i][0], box[i][1], box[i][2], 0.0f);
+			lb[1] = make_float4(box[i][3], box[i][4], box[i][5], 0.0f);
+		}
 	while (n < 8) {
 		int best = -1; float best_a = -1.0f;
 		for (uint32_t i = 0; i < n; i++) {
@@ -437,11 +445,13 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 	hipStream_t stream = (hipStream_t)stream_;
 	void *tmp[16] = {}; int n_tmp = 0;
 	DevNode *nodes = nullptr; TriHot *hot = nullptr; TriCold *cold = nullptr; Dev4Node *nodes4 = nullptr; Dev8Node *nodes8 = nullptr;
+	float *leaf_box = nullptr;
 	auto cleanup = [&] {
 		for (int i = 0; i < n_tmp; i++) if (tmp[i]) (void)hipFree(tmp[i]);
 		if (nodes) (void)hipFree(nodes);
 		if (nodes4) (void)hipFree(nodes4);
 		if (nodes8) (void)hipFree(nodes8);
+		if (leaf_box) (void)hipFree(leaf_box);
 		if (hot) (void)hipFree(hot);
 		if (cold) (void)hipFree(cold);
 	};
@@ -464,7 +474,7 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 	ok = ok && hipMalloc(&nodes, (nn - 1) * sizeof(DevNode)) == hipSuccess && hipMalloc(&hot, nn * sizeof(TriHot) + 16) == hipSuccess &&
 			hipMalloc(&cold, nn * sizeof(TriCold)) == hipSuccess &&
 			(!want4 || hipMalloc(&nodes4, (nn - 1) * sizeof(Dev4Node)) == hipSuccess) &&
-			(!want8 || hipMalloc(&nodes8, (nn - 1) * sizeof(Dev8Node)) == hipSuccess);
+			(!want8 || (hipMalloc(&nodes8, (nn - 1) * sizeof(Dev8Node)) == hipSuccess && hipMalloc(&leaf_box, nn * 32) == hipSuccess));
 	if (!ok) { std::snprintf(err, err_len, "device build: out of device memory"); cleanup(); return MRT_ERR_OOM; }
 
 	const uint32_t blocks = (uint32_t)((nn + LBVH_WG - 1) / LBVH_WG);
@@ -495,7 +505,7 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 		}
 		hipLaunchKernelGGL(lbvh_verify_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, boxes, idx_b, node_depth, scal + 6, scal + 8);
 		if (want4) hipLaunchKernelGGL(lbvh_collapse4_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes4);
-		if (want8) hipLaunchKernelGGL(lbvh_collapse8_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes8, scal + 7);
+		if (want8) hipLaunchKernelGGL(lbvh_collapse8_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes8, leaf_box, scal + 7);
 		DB_TRY(hipGetLastError());
 		DB_TRY(hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, stream));
 		DB_TRY(hipStreamSynchronize(stream));
@@ -509,8 +519,8 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 	out->depth = h[6] + 1u; // pending entries on the deepest path + the sentinel
 	// 4-wide walk: every 4-wide node on a path leaves at most 3 entries pending and descends at least one binary level
 	out->nodes4 = nodes4; out->stack4 = nodes4 ? 3u * h[6] + 1u : 0u;
-	if (nodes8 && h[7] != 0u) { (void)hipFree(nodes8); nodes8 = nullptr; } // a box that fits no grid: go without this layout
-	out->nodes8 = nodes8; out->stack8 = nodes8 ? 7u * h[6] + 1u : 0u;
+	if (nodes8 && h[7] != 0u) { (void)hipFree(nodes8); (void)hipFree(leaf_box); nodes8 = nullptr; leaf_box = nullptr; } // a box that fits no grid: go without this layout
+	out->nodes8 = nodes8; out->leaf_box = leaf_box; out->stack8 = nodes8 ? 7u * h[6] + 1u : 0u;
 	for (int k = 0; k < 3; k++) { out->bounds_lo[k] = ord2f(h[k]); out->bounds_hi[k] = ord2f(h[3 + k]); }
 	return MRT_OK;
 }

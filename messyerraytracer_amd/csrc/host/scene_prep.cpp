@@ -288,6 +288,10 @@ int prepare_scene(const mrt_tri64 *tris, uint32_t n_tris, const mrt_bvh_node32 *
 		// phase 2 (parallel): the grid of every node and the outward-rounded child boxes on it
 		std::vector<Dev8Node> dev8(kids.size());
 		std::atomic<bool> bad{false};
+		// exact boxes of the leaves (every leaf is the child of exactly one 8-wide node): the walk checks a
+		// candidate hit against them, so the looser quantised boxes never change a result
+		float *leaf_box = (float *)std::calloc((size_t)n_tris * 8u, sizeof(float));
+		if (!leaf_box) bad = true;
 		auto quantise = [&](size_t first, size_t last) {
 			for (size_t w = first; w < last; w++) {
 				const Kids &k = kids[w];
@@ -314,6 +318,10 @@ int prepare_scene(const mrt_tri64 *tris, uint32_t n_tris, const mrt_bvh_node32 *
 				for (uint32_t i = 0; i < 8; i++) {
 					if (i >= k.n) { node.ref[i] = kSentinel; continue; }
 					node.ref[i] = k.ch[i].ref;
+					if (k.ch[i].ref >= kLeafBit && leaf_box) {
+						float *lb = leaf_box + (size_t)(k.ch[i].ref & 0x7FFFFFFFu) * 8u;
+						for (int a = 0; a < 3; a++) { lb[a] = k.ch[i].mn[a]; lb[4 + a] = k.ch[i].mx[a]; }
+					}
 					for (int a = 0; a < 3 && !bad; a++) {
 						// outward rounding, verified on the value the kernel will decode: fmaf(q, scale, org)
 						int ql = (int)std::floor(((double)k.ch[i].mn[a] - (double)node.org[a]) / (double)scale[a]);
@@ -346,8 +354,10 @@ int prepare_scene(const mrt_tri64 *tris, uint32_t n_tris, const mrt_bvh_node32 *
 				out->n_nodes8 = (uint32_t)dev8.size();
 				std::memcpy(out->nodes8, dev8.data(), dev8.size() * sizeof(Dev8Node));
 				out->stack8 = stack8;
+				out->leaf_box = leaf_box; leaf_box = nullptr;
 			}
 		}
+		std::free(leaf_box);
 	}
 	return MRT_OK;
 }

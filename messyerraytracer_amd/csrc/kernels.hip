@@ -291,8 +291,6 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 
 #include "lane_persistent_kernel.h"
 #include "packet_kernel.h"
-#include "packet4_kernel.h"
-#include "packet2_kernel.h"
 #include "packet_asm_kernel.h"
 
 // ---- standalone ray generation (mrt_generate_grid) ---------------------------------
@@ -536,28 +534,6 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 	if (p.kernel == MRT_KERNEL_PACKET_ASM && !count) { // counting builds use the C++ packet kernel
 		if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true>), grid, wg, 0, stream, p);
 		else hipLaunchKernelGGL((trace_packet_asm_kernel<false>), grid, wg, 0, stream, p);
-		return hipGetLastError();
-	}
-	if (p.kernel == MRT_KERNEL_PACKET2) { // two 64-ray groups per wave: half the workgroups
-		const uint64_t blocks2 = (threads + 2 * MRT_WG - 1) / (2 * MRT_WG);
-		dim3 grid2((uint32_t)blocks2);
-		if (any_hit) {
-			if (count) hipLaunchKernelGGL((trace_packet2_kernel<true, true>), grid2, wg, 0, stream, p);
-			else hipLaunchKernelGGL((trace_packet2_kernel<true, false>), grid2, wg, 0, stream, p);
-		} else {
-			if (count) hipLaunchKernelGGL((trace_packet2_kernel<false, true>), grid2, wg, 0, stream, p);
-			else hipLaunchKernelGGL((trace_packet2_kernel<false, false>), grid2, wg, 0, stream, p);
-		}
-		return hipGetLastError();
-	}
-	if (p.kernel == MRT_KERNEL_PACKET4) {
-		if (any_hit) {
-			if (count) hipLaunchKernelGGL((trace_packet4_kernel<true, true>), grid, wg, 0, stream, p);
-			else hipLaunchKernelGGL((trace_packet4_kernel<true, false>), grid, wg, 0, stream, p);
-		} else {
-			if (count) hipLaunchKernelGGL((trace_packet4_kernel<false, true>), grid, wg, 0, stream, p);
-			else hipLaunchKernelGGL((trace_packet4_kernel<false, false>), grid, wg, 0, stream, p);
-		}
 		return hipGetLastError();
 	}
 	if (p.kernel == MRT_KERNEL_PACKET || p.kernel == MRT_KERNEL_PACKET_ASM) {

@@ -65,6 +65,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 	const float4 *nodes = reinterpret_cast<const float4 *>(p.nodes);
 	const float4 *nodes4 = reinterpret_cast<const float4 *>(p.nodes4);
 	const float4 *nodes8 = reinterpret_cast<const float4 *>(p.nodes8);
+	const float4 *leaf_box = reinterpret_cast<const float4 *>(p.leaf_box);
 	const float4 *hot = reinterpret_cast<const float4 *>(p.tri_hot);
 
 	// per-lane ray state
@@ -289,6 +290,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 			// LEAF phase: every lane at a leaf intersects that leaf (glsl:166-192), then pops
 			if (cur >= kLeafBit) {
 				uint32_t slot = cur & 0x7FFFFFFFu;
+				const uint32_t leaf_first = slot;
 				bool last;
 				do {
 					const float4 *t3 = hot + (size_t)slot * 3u;
@@ -312,8 +314,27 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 									const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
 									const uint32_t id = __float_as_uint(q0.w);
 									if (!(t < r.t_min) && (t < best_t || (t == best_t && best_slot != 0xFFFFFFFFu && id < best_id))) {
-										best_t = t; best_u = u; best_v = v; best_slot = slot; best_id = id;
-										if (ANY_HIT) last = true;
+										// 8-wide: the quantised boxes that led here are looser than the exact ones; accept
+										// the hit only if the ray passes the slab test on the leaf's exact box, as it does
+										// in the 2-wide walk (nested boxes: that is passing every ancestor's test too).
+										// The far limit is the ray's own t_max, not the best hit so far: which hits are
+										// accepted must not depend on the order the leaves were reached in (two hits at
+										// the same t in different leaves: the lower id has to win whichever came first).
+										bool entered = true;
+										if (WIDTH == 8) {
+											const float4 *lb = leaf_box + (size_t)leaf_first * 2u;
+											const float4 mn = lb[0], mx = lb[1];
+											const float x0 = fma_(mn.x, ix, nrx), x1 = fma_(mx.x, ix, nrx);
+											const float y0 = fma_(mn.y, iy, nry), y1 = fma_(mx.y, iy, nry);
+											const float z0 = fma_(mn.z, iz, nrz), z1 = fma_(mx.z, iz, nrz);
+											const float tnear = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), r.t_min));
+											const float tfar = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), r.t_max));
+											entered = tnear <= tfar;
+										}
+										if (entered) {
+											best_t = t; best_u = u; best_v = v; best_slot = slot; best_id = id;
+											if (ANY_HIT) last = true;
+										}
 									}
 								}
 							}

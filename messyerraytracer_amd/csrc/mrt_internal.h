@@ -59,7 +59,11 @@ static_assert(sizeof(Dev4Node) == 128, "Dev4Node must be 128 bytes");
 // builder rounds outwards and checks the DECODED value in float, so a decoded box contains the exact
 // one and the slab test on it (same formula as for exact boxes, monotone in the box coordinate)
 // passes whenever the test on the exact box does: the walk visits a superset of what the 2-wide walk
-// visits, and every triangle is still tested with the exact arithmetic.
+// visits, and every triangle is still tested with the exact arithmetic.  A hit is accepted only if
+// the ray also passes the slab test on the leaf's EXACT box (leaf_box[], 32 bytes per leaf, read on
+// that rare path only): boxes nest and the slab arithmetic is monotone, so passing the leaf's box is
+// passing every ancestor's, and the 8-wide walk reports exactly what the 2-wide walk reports -- also
+// for rays that lie in a face plane of a box, where a looser box would let an edge hit through.
 struct alignas(16) Dev8Node {
 	float org[3];
 	uint8_t exp[3];       // float exponent byte of the grid step per axis
@@ -85,6 +89,7 @@ struct TraceParams {
 	const DevNode *nodes;
 	const Dev4Node *nodes4;    // packet kernel, 4-wide layout (may be null)
 	const Dev8Node *nodes8;    // 8-wide compressed layout (may be null)
+	const float *leaf_box;     // with nodes8: exact box {min xyz, -, max xyz, -} of the leaf that starts at a slot
 	const TriHot *tri_hot;
 	const TriCold *tri_cold;
 	const void *rays;          // IN_RAY32 / IN_HOST60 (device)
@@ -115,6 +120,7 @@ struct DeviceSceneHost {
 	uint32_t stack4 = 0;        // per-wave stack entries the 4-wide walk can need
 	bool want8 = false;         // in: also build the 8-wide compressed collapse
 	Dev8Node *nodes8 = nullptr; uint32_t n_nodes8 = 0; uint32_t stack8 = 0;
+	float *leaf_box = nullptr;  // with nodes8: 8 floats per triangle slot, filled at the first slot of every leaf
 	float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0}; // scene AABB (sort key quantisation)
 	TriHot *hot = nullptr; TriCold *cold = nullptr; uint32_t n_tris = 0;
 	uint32_t depth = 0;         // max stack entries any traversal can need (incl. sentinel)
@@ -129,6 +135,7 @@ struct DeviceBuildResult {
 	DevNode *nodes = nullptr; TriHot *hot = nullptr; TriCold *cold = nullptr;
 	Dev4Node *nodes4 = nullptr;  // optional: one 4-wide node per binary node, at the binary node's index
 	Dev8Node *nodes8 = nullptr;  // optional: likewise for the 8-wide compressed layout
+	float *leaf_box = nullptr;   // with nodes8: exact leaf boxes, 8 floats per slot
 	uint32_t n_nodes = 0, n_tris = 0, depth = 0, stack4 = 0, stack8 = 0;
 	float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
 };

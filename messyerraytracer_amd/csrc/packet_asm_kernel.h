@@ -15,7 +15,8 @@
 //     of two popcount votes: order only affects speed, never results;
 //   * the per-wave stack is addressed through a VGPR (uniform LDS byte address), with a
 //     sentinel at the bottom, so push/pop cost no scalar instruction and there is no
-//     empty-stack test;
+//     empty-stack test; an entry also carries the mask of the lanes whose own ray hit the
+//     pushed child's box (needed when it is a leaf: see packet_kernel.h);
 //   * one s_load_dwordx16 with an SGPR offset fetches the 64-byte node.
 // The slab test is the octant-specialised one of packet_kernel.h: 12 v_fma + 8
 // v_max/v_min(3) + 2 v_cmp, bit-identical values.  Leaves (triangle tests) stay in C++.
@@ -25,21 +26,15 @@
 // node registers after the s_load_dwordx16 into s[36:51]:
 //   s36..s38 lmin.xyz  s39 left_ref | s40..s42 lmax.xyz  s43 right_ref
 //   s44..s46 rmin.xyz  s47 -        | s48..s50 rmax.xyz  s51 -
-// scratch: s52 byte offset, s53 far ref, s[54:55] right-child mask, v40..v51 slab values.
-// Optional: when a far child is pushed, touch its node with a 4-byte scalar load so the line is
-// in the scalar cache / L2 by the time it is popped (s57 is never read; a leaf ref touches node 0).
-#ifdef MRT_PREFETCH_FAR
-#define MRT_ASM_PREFETCH_FAR                                                                               \
-		"s_cmp_lt_u32 s53, 0x7fffffff\n"                                                                    \
-		"s_cselect_b32 s56, s53, 0\n"                                                                       \
-		"s_lshl_b32 s56, s56, 6\n"                                                                          \
-		"s_load_dword s57, %[base], s56\n"
-// the touch may still be in flight when the block ends; s57 is only reserved inside the block
-#define MRT_ASM_EXIT_WAIT "s_waitcnt lgkmcnt(0)\n"
-#else
-#define MRT_ASM_PREFETCH_FAR
-#define MRT_ASM_EXIT_WAIT
-#endif
+// scratch: s52 byte offset, s53 far ref, s[54:55] right-child mask, s[56:57] "left is nearer" flags,
+// s[58:59] mask of the pushed (far) child, s[60:61] mask of the entered child, v40..v51 slab values.
+//
+// Stack entries are 16 bytes: {ref, -, lane mask (64 bit)}.  The mask holds the lanes whose OWN ray hit the
+// box of the pushed child; it matters only when that child is a leaf (packet_kernel.h: a lane accepts
+// triangle hits only in leaves its own ray entered).  The block ends with `node` a leaf or the sentinel and
+// the leaf's mask at LDS [sp + 8]: left there by the pop, or written on the way out when the leaf was
+// entered straight from its parent.  Inner steps pay nothing for this; a push pays one s_cselect_b64, two
+// v_mov and a ds_write_b64.
 #define MRT_ASM_NODE_LOOP(LNX, LFX, LNY, LFY, LNZ, LFZ, RNX, RFX, RNY, RFY, RNZ, RFZ)                      \
 	asm volatile(                                                                                           \
 		"s_cmp_eq_u32 %[dopop], 1\n"                                                                        \
@@ -74,38 +69,50 @@
 		"s_cbranch_vccz L_lmiss_%=\n"                                                                       \
 		"s_cmp_eq_u64 s[54:55], 0\n"                                                                        \
 		"s_cbranch_scc1 L_onlyl_%=\n"                                                                       \
-		"v_cmp_lt_f32 vcc, v40, v46\n"      /* both hit: lane 0 decides which is nearer */               \
-		"s_bitcmp1_b32 vcc_lo, 0\n"                                                                         \
+		"v_cmp_lt_f32_e64 s[56:57], v40, v46\n" /* both hit: lane 0 decides which is nearer */              \
+		"s_bitcmp1_b32 s56, 0\n"                                                                            \
 		"s_cselect_b32 s53, s43, s39\n"     /* far  */                                                   \
 		"s_cselect_b32 %[node], s39, s43\n" /* near */                                                   \
+		"s_cselect_b64 s[58:59], s[54:55], vcc\n" /* lanes that hit the far child  */                     \
+		"s_cselect_b64 s[60:61], vcc, s[54:55]\n" /* lanes that hit the near child */                     \
 		"v_mov_b32 v41, s53\n"                                                                              \
+		"v_mov_b32 v42, s58\n"                                                                              \
+		"v_mov_b32 v43, s59\n"                                                                              \
 		"ds_write_b32 %[sp], v41\n"                                                                         \
-		"v_add_u32 %[sp], 4, %[sp]\n"                                                                       \
-		MRT_ASM_PREFETCH_FAR                                                                                \
-		"s_branch L_check_%=\n"                                                                             \
+		"ds_write_b64 %[sp], v[42:43] offset:8\n"                                                           \
+		"v_add_u32 %[sp], 16, %[sp]\n"                                                                      \
+		"s_branch L_entered_%=\n"                                                                           \
 		"L_onlyl_%=:\n"                                                                                     \
 		"s_mov_b32 %[node], s39\n"                                                                          \
-		"s_branch L_check_%=\n"                                                                             \
+		"s_mov_b64 s[60:61], vcc\n"                                                                         \
+		"s_branch L_entered_%=\n"                                                                           \
 		"L_lmiss_%=:\n"                                                                                     \
 		"s_cmp_eq_u64 s[54:55], 0\n"                                                                        \
 		"s_cbranch_scc1 L_pop_%=\n"                                                                         \
 		"s_mov_b32 %[node], s43\n"                                                                          \
-		"s_branch L_check_%=\n"                                                                             \
+		"s_mov_b64 s[60:61], s[54:55]\n"                                                                    \
+		"L_entered_%=:\n"                   /* a child entered straight from its parent */               \
+		"s_cmp_lt_u32 %[node], 0x7fffffff\n"                                                                \
+		"s_cbranch_scc1 L_node_%=\n"                                                                        \
+		"v_mov_b32 v42, s60\n"              /* a leaf: its lane mask goes where a pop would leave it */  \
+		"v_mov_b32 v43, s61\n"                                                                              \
+		"ds_write_b64 %[sp], v[42:43] offset:8\n"                                                           \
+		"s_branch L_exit_%=\n"                                                                              \
 		"L_pop_%=:\n"                                                                                       \
-		"v_add_u32 %[sp], -4, %[sp]\n"                                                                      \
+		"v_add_u32 %[sp], -16, %[sp]\n"                                                                     \
 		"ds_read_b32 v41, %[sp]\n"                                                                          \
 		"s_waitcnt lgkmcnt(0)\n"                                                                            \
 		"v_readfirstlane_b32 %[node], v41\n"                                                                \
 		"L_check_%=:\n"                                                                                     \
 		"s_cmp_lt_u32 %[node], 0x7fffffff\n"                                                                \
 		"s_cbranch_scc1 L_node_%=\n"                                                                        \
-		MRT_ASM_EXIT_WAIT                                                                                   \
+		"L_exit_%=:\n"                                                                                      \
 		: [node] "+s"(node), [sp] "+v"(sp)                                                                  \
 		: [base] "s"(base), [dopop] "s"(dopop), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), [nrx] "v"(nrx),   \
 		  [nry] "v"(nry), [nrz] "v"(nrz), [tmin] "v"(tmin), [lim] "v"(lim)                                  \
 		: "vcc", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45",      \
-		  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "v40", "v41", "v42", "v43", \
-		  "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51")
+		  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", \
+		  "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51")
 
 // Walks inner nodes until `node` is a leaf reference (>= 0x80000000) or the sentinel
 // (0x7FFFFFFF = the stack ran empty).  dopop = 1: start by popping (after a leaf).
@@ -140,7 +147,11 @@ __device__ __forceinline__ void packet_traverse_asm(const TraceParams &p, const 
 		packet_node_loop_asm<OCT>(p.nodes, cur, sp, dopop, ix, iy, iz, nrx, nry, nrz, r.t_min, lim_t);
 		cur = __builtin_amdgcn_readfirstlane(cur);
 		if (cur == kSentinel) break;
-		// leaf: every lane tests every triangle of the leaf (glsl:166-192)
+		// leaf: the lanes whose own ray hit its box test its triangles (glsl:166-192); their mask lies at
+		// [sp + 8] (volatile: written by the asm block, which the compiler does not know to write memory)
+		const unsigned long long own_mask =
+				*(volatile __attribute__((address_space(3))) unsigned long long *)(uintptr_t)(sp + 8u);
+		float lim_leaf = ((own_mask >> (threadIdx.x & (MRT_WAVE - 1))) & 1ull) != 0ull ? lim_t : -FLT_MAX;
 		uint32_t slot = cur & 0x7FFFFFFFu;
 		bool last;
 		do {
@@ -165,9 +176,9 @@ __device__ __forceinline__ void packet_traverse_asm(const TraceParams &p, const 
 						if (!(v < 0.0f || u + v > 1.0f)) {
 							const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
 							const uint32_t id = __float_as_uint(q0.w);
-							if (!(t < r.t_min) && (t < lim_t || (t == lim_t && best_slot != 0xFFFFFFFFu && id < best_id))) {
+							if (!(t < r.t_min) && (t < lim_leaf || (t == lim_leaf && best_slot != 0xFFFFFFFFu && id < best_id))) {
 								best_t = t; best_u = u; best_v = v; best_slot = slot; best_id = id;
-								lim_t = ANY_HIT ? -FLT_MAX : t;
+								lim_t = lim_leaf = ANY_HIT ? -FLT_MAX : t;
 							}
 						}
 					}
@@ -183,7 +194,8 @@ __device__ __forceinline__ void packet_traverse_asm(const TraceParams &p, const 
 template <bool ANY_HIT>
 __global__ __launch_bounds__(MRT_WG) void trace_packet_asm_kernel(const TraceParams p)
 {
-	__shared__ uint32_t wave_stack[MRT_WG / MRT_WAVE][MRT_PACKET_STACK + 1];
+	// 16-byte stack entries {ref, -, lane mask}; entry 0 holds the sentinel
+	__shared__ __attribute__((aligned(16))) uint32_t wave_stack[MRT_WG / MRT_WAVE][(MRT_PACKET_STACK + 1) * 4];
 	if (skip_launch(p)) return;
 	uint32_t block = blockIdx.x;
 	if (p.xcd_swizzle) {
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_packet_asm_kernel(const TracePar
 		// (volatile: the asm block has no "memory" clobber — it only reads read-only scene data and this
 		// private stack — so that the compiler keeps the triangle fetches of the leaf code scalar)
 		*(volatile uint32_t *)&stack[0] = kSentinel;
-		const uint32_t sp = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(stack + 1);
+		const uint32_t sp = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(stack + 4);
 #define MRT_PKTA(O) case O: packet_traverse_asm<O, ANY_HIT>(p, r, sp, best_t, best_u, best_v, best_slot); break;
 		switch (oct) { MRT_PKTA(0) MRT_PKTA(1) MRT_PKTA(2) MRT_PKTA(3) MRT_PKTA(4) MRT_PKTA(5) MRT_PKTA(6) MRT_PKTA(7) }
 #undef MRT_PKTA

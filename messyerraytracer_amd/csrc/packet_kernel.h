@@ -6,10 +6,13 @@
 // wave through the scalar cache (s_load_dwordx8 x2) instead of 64 x 4 vector
 // loads, the traversal stack is one LDS dword per level per WAVE (256 B), and the
 // per-child decisions are wave ballots.  A child is visited when ANY lane hits
-// its box; lanes that miss it ride along (their slab / triangle tests fail on
-// their own), so every lane still tests every triangle of every leaf its own ray
-// reaches and the per-lane results are exactly those of the lane kernel (the
-// triangle test decides; boxes only cull).
+// its box; lanes that miss it ride along.  In a LEAF a lane accepts triangle hits
+// only if its own ray passed the box test of that leaf (the bit is kept with the
+// stack entry when a leaf is pushed): child boxes are nested and the slab test is
+// monotone in the box coordinate, so passing a leaf's box implies passing every
+// ancestor's, and each lane ends up testing exactly the leaves its own one-ray
+// walk would test -- also for a ray that grazes a box face, where a slab test
+// (rounded) and the triangle test (rounded otherwise) can disagree.
 //
 // Octant specialisation: when every ray of the packet has the same direction
 // signs (true for almost every primary-ray tile), min(t0,t1) / max(t0,t1) of the
@@ -36,6 +39,8 @@ __device__ __forceinline__ void packet_traverse(const TraceParams &p, const RayR
 	uint32_t sp = 0;   // wave-uniform
 	uint32_t cur = 0;  // wave-uniform: the root is always a wide node
 	bool popped = false;
+	unsigned long long own_bits = 0ull; // bit k: this lane's own ray hit the box of stack entry k
+	bool own = true;                    // ... of the node in `cur` (used when it is a leaf)
 
 	for (;;) {
 		cur = __builtin_amdgcn_readfirstlane(cur);
@@ -76,14 +81,17 @@ __device__ __forceinline__ void packet_traverse(const TraceParams &p, const RayR
 				// order: the child that more lanes would enter first goes first
 				const unsigned long long lfirst = __ballot(hl && (!hr || tl < tr));
 				const bool left_near = 2 * __builtin_popcountll(lfirst) >= __builtin_popcountll(ml | mr);
-				stack[sp] = left_near ? rref : lref; sp++;
-				cur = left_near ? lref : rref;
+				stack[sp] = left_near ? rref : lref;
+				own_bits = (left_near ? hr : hl) ? (own_bits | (1ull << sp)) : (own_bits & ~(1ull << sp));
+				sp++;
+				cur = left_near ? lref : rref; own = left_near ? hl : hr;
 				continue;
 			}
-			if (ml != 0ull) { cur = lref; continue; }
-			if (mr != 0ull) { cur = rref; continue; }
+			if (ml != 0ull) { cur = lref; own = hl; continue; }
+			if (mr != 0ull) { cur = rref; own = hr; continue; }
 		} else {
-			// leaf: every lane tests every triangle of the leaf (glsl:166-192)
+			// leaf: every lane whose own ray hit the leaf's box tests its triangles (glsl:166-192)
+			float lim_leaf = own ? lim_t : -FLT_MAX;
 			uint32_t slot = cur & 0x7FFFFFFFu;
 			bool last;
 			do {
@@ -110,9 +118,9 @@ __device__ __forceinline__ void packet_traverse(const TraceParams &p, const RayR
 								const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
 								// lim_t == best_t for live lanes; exact ties go to the lower triangle id
 								const uint32_t id = __float_as_uint(q0.w);
-								if (!(t < r.t_min) && (t < lim_t || (t == lim_t && best_slot != 0xFFFFFFFFu && id < best_id))) {
+								if (!(t < r.t_min) && (t < lim_leaf || (t == lim_leaf && best_slot != 0xFFFFFFFFu && id < best_id))) {
 									best_t = t; best_u = u; best_v = v; best_slot = slot; best_id = id;
-									lim_t = ANY_HIT ? -FLT_MAX : t; // any-hit: this lane is done
+									lim_t = lim_leaf = ANY_HIT ? -FLT_MAX : t; // any-hit: this lane is done
 								}
 							}
 						}
@@ -124,6 +132,7 @@ __device__ __forceinline__ void packet_traverse(const TraceParams &p, const RayR
 		}
 		if (sp == 0) break;
 		sp--; cur = stack[sp];
+		own = ((own_bits >> sp) & 1ull) != 0ull;
 		popped = true;
 	}
 }

@@ -180,3 +180,33 @@ def test_instances_flattened_and_built_on_the_device(built):
         c.build_instanced_scene_device(local, bad)
     c.device_free(d_out); c.device_free(d_local)
     c.close()
+
+
+def test_a_tree_deeper_than_the_stack_is_refused_not_walked(built):
+    """An adversarial scene -- one triangle per Morton-key bit (a 63-deep chain in the radix tree) plus 64
+    coincident ones at its end -- gives an LBVH deeper than the 64-entry packet stack: the device build
+    must say so (MRT_ERR_UNSUPPORTED) and leave the context usable for the host-built tree of the scene."""
+    pts = []
+    for k in range(63):
+        bit = 62 - k                      # key bit 3t + axis holds bit t of that axis' grid coordinate
+        p = [0.0, 0.0, 0.0]
+        p[bit % 3] = float(1 << (bit // 3))
+        pts.append(p)
+    pts.append([float((1 << 21) - 1)] * 3)   # fixes the scene extent at 2^21 - 1 grid cells of size 1
+    pts += [[0.0, 0.0, 0.0]] * 64
+    c0 = np.array(pts, dtype=np.float32)
+    v = np.zeros((c0.shape[0], 3, 3), dtype=np.float32)
+    v[:, 0] = c0 + np.float32([0.1, 0.1, 0.1]); v[:, 1] = c0 + np.float32([0.4, 0.1, 0.2]); v[:, 2] = c0 + np.float32([0.1, 0.4, 0.3])
+    c = capi.Context(0)
+    with pytest.raises(capi.MrtError) as e:
+        c.build_scene_device(capi.make_triangles(v))
+    assert e.value.status == capi.ERR_UNSUPPORTED
+    assert not c.is_available()           # no half-installed scene
+    scene, osc = capi.Scene(v), po.OracleScene(v)
+    scene.upload(c)
+    rays = np.zeros(256, dtype=T.RAY32)
+    rays["origin"] = np.float32([0.2, 0.2, -5.0]) + np.float32([1.0, 0.0, 0.0]) * (np.arange(256, dtype=np.float32)[:, None] * 0.01)
+    rays["direction"] = [0.0, 0.0, 1.0]
+    rays["t_min"], rays["t_max"] = 0.001, T.FLT_MAX
+    parity.assert_exact(c.cast(rays, flags=capi.FLAG_COHERENT), osc.trace(rays), "host tree after a refused device build")
+    c.close()

@@ -670,3 +670,59 @@ def test_c5_multi_mesh_sharded_rows(ctx):
     assert hits_total > 0.5 * w * h
     osc = po.OracleScene(verts)
     parity.assert_exact(band, osc.trace(osc_rows), "C5 one row vs oracle")
+
+
+def _tiled_wall(n=12, pitch=1.0):
+    """An axis-aligned wall of n x n square tiles (two triangles each) at z = 0 plus a second, offset layer at
+    z = 1.5 * pitch: every triangle edge lies on a multiple of the pitch, i.e. on faces of leaf and inner boxes."""
+    tris = []
+    for z, off in ((0.0, 0.0), (1.5 * pitch, 0.5)):
+        for i in range(n):
+            for j in range(n):
+                x0, y0, x1, y1 = (i + off) * pitch, (j + off) * pitch, (i + off + 1) * pitch, (j + off + 1) * pitch
+                a, b, c, d = (x0, y0, z), (x1, y0, z), (x1, y1, z), (x0, y1, z)
+                tris += [(a, b, c), (a, c, d)]
+    return np.array(tris, dtype=np.float32)
+
+
+@pytest.mark.parametrize("pitch", [1.0, 0.3, 0.7])
+@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM,
+                                    capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT, capi.KERNEL_LANE8_PERSISTENT])
+def test_rays_that_graze_box_faces(built, kernel, pitch):
+    """Axis-parallel rays whose origins lie exactly on tile edges: the ray runs IN a face plane of leaf and
+    inner boxes, where the rounded slab test (direction component 0 -> inverse 1e9) and the triangle test
+    can disagree.  The oracle walks the tree ray by ray; every kernel must give the same answers:
+    a lane of a packet may only accept hits in leaves its OWN ray entered, and the 8-wide kernel, whose
+    quantised boxes are looser than the tree's (pitch 0.3 is not on its power-of-two grids), only accepts a
+    hit if the ray passes the leaf's exact box (Arithmetic)."""
+    v = _tiled_wall(12, pitch)
+    scene, osc = capi.Scene(v), po.OracleScene(v)
+    c = capi.Context(0, kernel=kernel)
+    scene.upload(c)
+    xs = (np.arange(0.0, 12.5, 0.25) * pitch).astype(np.float32)   # every 4th origin coordinate is a tile edge
+    gx, gy = np.meshgrid(xs, xs, indexing="xy")
+    n = gx.size
+    rays = np.zeros(n, dtype=T.RAY32)
+    rays["origin"][:, 0], rays["origin"][:, 1], rays["origin"][:, 2] = gx.ravel(), gy.ravel(), -3.0
+    rays["direction"] = [0.0, 0.0, 1.0]
+    rays["t_min"], rays["t_max"] = 0.001, T.FLT_MAX
+    side = rays.copy()                                          # along the wall, inside its plane and just off it
+    side["origin"][:, 0], side["origin"][:, 1] = -2.0, gy.ravel()
+    side["origin"][:, 2] = np.where(np.arange(n) % 2 == 0, 0.0, np.float32(1.5 * pitch))
+    side["direction"] = [1.0, 0.0, 0.0]
+    diag = rays.copy()
+    d = np.float32(1.0) / np.sqrt(np.float32(2.0))
+    diag["direction"] = [d, 0.0, d]
+    for batch, name in ((rays, "normal"), (side, "in-plane"), (diag, "diagonal"), (np.concatenate([rays, side, diag]), "mixed")):
+        want = osc.trace(batch)
+        for flags in (capi.FLAG_COHERENT, 0):
+            parity.assert_exact(c.cast(batch, flags=flags), want, f"graze {name} kernel={kernel} flags={flags}")
+        b = c.cast(batch, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_COHERENT | capi.FLAG_BOOL_OUT)
+        assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
+    # a batch large enough for the persistent kernels (AUTO: the 8-wide one)
+    big = np.tile(np.concatenate([rays, side, diag]), 12)
+    want = osc.trace(big)
+    for flags in (capi.FLAG_COHERENT, 0):
+        parity.assert_exact(c.cast(big, flags=flags), want, f"graze big kernel={kernel} flags={flags}")
+    assert int((want["prim_id"] >= 0).sum()) > n and int((want["prim_id"] < 0).sum()) > 0
+    c.close()

@@ -35,12 +35,6 @@ VARIANTS = {
     "packet_tile8x8_zorder": (dict(kernel=capi.KERNEL_PACKET, tile_order=2), "tiled"),
     "packet_tile8x8_zorder_swz": (dict(kernel=capi.KERNEL_PACKET, tile_order=2, xcd_swizzle=1), "tiled"),
     "lane_tile8x8_zorder": (dict(kernel=capi.KERNEL_LANE, tile_order=2), "tiled"),
-    "packet4_tile8x8": (dict(kernel=capi.KERNEL_PACKET4), "tiled"),
-    "packet4_linear": (dict(kernel=capi.KERNEL_PACKET4), "cast"),
-    "packet4_tile16x4": (dict(kernel=capi.KERNEL_PACKET4, tile_w_log2=4), "tiled"),
-    "packet2_tile8x8": (dict(kernel=capi.KERNEL_PACKET2), "tiled"),
-    "packet2_linear": (dict(kernel=capi.KERNEL_PACKET2), "cast"),
-    "packet2_fused": (dict(kernel=capi.KERNEL_PACKET2), "fused"),
     "asm_tile8x8": (dict(kernel=capi.KERNEL_PACKET_ASM), "tiled"),
     "asm_linear": (dict(kernel=capi.KERNEL_PACKET_ASM), "cast"),
     "asm_fused": (dict(kernel=capi.KERNEL_PACKET_ASM), "fused"),
@@ -112,12 +106,12 @@ def main():
         summary[n] = dict(min_ms=float(v.min()), median_ms=float(np.median(v)), mrays=w * h / np.median(v) / 1e3)
         print(f"{n:28s} {v.min():9.3f} {np.median(v):10.3f} {w * h / np.median(v) / 1e3:13.1f}", flush=True)
     if a.count:
-        for kern in (capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET4, capi.KERNEL_PACKET2):
+        for kern in (capi.KERNEL_LANE, capi.KERNEL_PACKET):
             c = capi.Context(0, kernel=kern, count_visits=True)
             scene.upload(c)
             c.cast_tiled(d_rays, d_hits, w, h)
             s = c.stats()
-            print("counting", {1: "lane", 2: "packet", 3: "packet4", 4: "packet2"}[kern], "nodes/ray %.1f tris/ray %.2f max_stack %d dead_pops/ray %.2f" % (
+            print("counting", {1: "lane", 2: "packet"}[kern], "nodes/ray %.1f tris/ray %.2f max_stack %d dead_pops/ray %.2f" % (
                 s["bvh_nodes_visited"] / s["rays_cast"], s["tri_tests"] / s["rays_cast"], s["max_stack_depth"], s["dead_pops"] / s["rays_cast"]), flush=True)
             c.close()
     print(json.dumps(summary))
