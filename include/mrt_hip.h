@@ -231,6 +231,17 @@ int mrt_pack_host_triangles(const mrt_host_tri80 *tris, uint32_t n_tris, mrt_tri
 int mrt_bvh2_build(const float *verts4, uint32_t n_tris, mrt_bvh_node32 *nodes,
 		uint32_t *prim_idx, uint32_t *used_nodes, uint32_t n_threads);
 
+/* BVH cache file, the counterpart of tinybvh::BVH::Save / Load (tiny_bvh.h:1747-1799): a scene
+ * that did not change is not rebuilt.  The file holds used_nodes nodes and n_tris prim indices
+ * behind a 32-byte header (magic, version, counts, checksum).  mrt_bvh2_load accepts a file only
+ * for the triangle count it was saved for (as the reference does) and only if the checksum holds:
+ * MRT_ERR_BAD_BVH otherwise, MRT_ERR_INVALID if the file cannot be opened.  nodes must hold
+ * 2*n_tris entries, prim_idx n_tris.  Host-only; the triangles are not stored. */
+int mrt_bvh2_save(const char *path, const mrt_bvh_node32 *nodes, uint32_t used_nodes,
+		const uint32_t *prim_idx, uint32_t n_tris);
+int mrt_bvh2_load(const char *path, uint32_t n_tris, mrt_bvh_node32 *nodes, uint32_t *prim_idx,
+		uint32_t *used_nodes);
+
 /* ---- scene upload: GPURayCaster::upload_scene (gpu_ray_caster.cpp:193-341) ---
  * tris are in original order (tris[i] is the triangle with prim index i in
  * prim_idx[]); the leaf -> prim_idx -> triangle indirection is resolved here
@@ -277,6 +288,25 @@ int mrt_flatten_instances(mrt_ctx *ctx, const float *verts9, uint32_t n_mesh_tri
 /* mrt_flatten_instances into a scratch buffer + mrt_build_scene_device over it. */
 int mrt_build_instanced_scene_device(mrt_ctx *ctx, const float *verts9, uint32_t n_mesh_tris,
 		const mrt_instance *instances, uint32_t n_instances, uint32_t flags);
+
+/* ---- two-level scene: SceneTLAS + MeshBLAS + BLASInstance (src/accel/scene_tlas.h:140-251,
+ * mesh_blas.h:86-138, blas_instance.h:47-107; tinybvh::BVH::IntersectTLAS, tiny_bvh.h:3306-3380).
+ * Nothing is flattened: one BVH (binned SAH) per distinct mesh in mesh space, one BVH over the
+ * instances' world boxes; a ray entering an instance is taken to mesh space by the inverse
+ * transform without renormalising its direction, so t stays world-parameterised.  Hit records:
+ * prim_id = the FLAT id of raytracer_server.cpp:700-711 (the instance's running triangle offset +
+ * the mesh-local index; the reference's TLAS path reports the local index, SURVEY.md section 0
+ * item 3), hit_layers = the instance's mask (whole instances are skipped by the query mask),
+ * normal = normalize(basis * mesh-space normal), position on the world ray.  Every cast entry
+ * point works on such a scene (one lane per ray); hit tokens do not (MRT_ERR_UNSUPPORTED).
+ * verts9 / instances: host arrays.  Transforms must be invertible (MRT_ERR_INVALID). */
+int mrt_upload_two_level_scene(mrt_ctx *ctx, const float *verts9, uint32_t n_mesh_tris,
+		const mrt_instance *instances, uint32_t n_instances);
+/* SceneTLAS::set_instance_transform + refit_tlas (scene_tlas.h:118-134,178-196): the same
+ * instances (same meshes, same order) with new transforms / masks.  Only the top level is rebuilt
+ * and re-uploaded (n_instances rows + fewer than 2 n_instances nodes). */
+int mrt_update_instances(mrt_ctx *ctx, const mrt_instance *instances, uint32_t n_instances);
+
 int mrt_is_available(const mrt_ctx *ctx);      /* initialized && scene uploaded */
 int mrt_scene_info(const mrt_ctx *ctx, uint32_t *n_tris, uint32_t *n_wide_nodes, uint32_t *bvh_depth);
 

@@ -26,8 +26,8 @@ KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET, KERNEL_PACKET4, KERNEL_PACKET2, KERNEL_
 # every entry point include/mrt_hip.h declares (tests check they are all exported)
 SYMBOLS = [
     "mrt_create", "mrt_destroy", "mrt_last_error", "mrt_status_string", "mrt_version", "mrt_set_stream",
-    "mrt_synchronize", "mrt_make_triangles", "mrt_pack_host_triangles", "mrt_bvh2_build", "mrt_upload_scene",
-    "mrt_build_scene_device", "mrt_flatten_instances", "mrt_build_instanced_scene_device", "mrt_is_available", "mrt_scene_info", "mrt_cast", "mrt_submit", "mrt_collect", "mrt_has_pending",
+    "mrt_synchronize", "mrt_make_triangles", "mrt_pack_host_triangles", "mrt_bvh2_build", "mrt_bvh2_save", "mrt_bvh2_load", "mrt_upload_scene",
+    "mrt_build_scene_device", "mrt_flatten_instances", "mrt_build_instanced_scene_device", "mrt_upload_two_level_scene", "mrt_update_instances", "mrt_is_available", "mrt_scene_info", "mrt_cast", "mrt_submit", "mrt_collect", "mrt_has_pending",
     "mrt_camera_look", "mrt_generate_grid", "mrt_cast_grid", "mrt_cast_tiled", "mrt_expand_tokens",
     "mrt_expand_grid_tokens", "mrt_morton_keys",
     "mrt_get_stats", "mrt_device_alloc", "mrt_device_free", "mrt_memcpy_h2d", "mrt_memcpy_d2h",
@@ -85,10 +85,14 @@ def load():
     L.mrt_make_triangles.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p]
     L.mrt_pack_host_triangles.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
     L.mrt_bvh2_build.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_uint32]
+    L.mrt_bvh2_save.argtypes = [C.c_char_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.mrt_bvh2_load.argtypes = [C.c_char_p, C.c_uint32, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32)]
     L.mrt_upload_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
     L.mrt_build_scene_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
     L.mrt_flatten_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     L.mrt_build_instanced_scene_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.mrt_upload_two_level_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.mrt_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.mrt_is_available.argtypes = [C.c_void_p]
     L.mrt_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
     L.mrt_cast.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_uint32]
@@ -150,6 +154,28 @@ def bvh2_build(verts4: np.ndarray, n_threads: int = 0):
     rc = load().mrt_bvh2_build(_np(v4), n, _np(nodes), _np(prim_idx), C.byref(used), n_threads)
     if rc:
         raise MrtError(rc, "mrt_bvh2_build")
+    return nodes[:used.value].copy(), prim_idx, used.value
+
+
+def bvh2_save(path: str, nodes: np.ndarray, prim_idx: np.ndarray) -> None:
+    """BVH cache file (the counterpart of tinybvh::BVH::Save, tiny_bvh.h:1747-1758)."""
+    nodes = np.ascontiguousarray(nodes)
+    prim_idx = np.ascontiguousarray(prim_idx, dtype=np.uint32)
+    assert nodes.dtype == T.NODE32
+    rc = load().mrt_bvh2_save(os.fsencode(path), _np(nodes), nodes.shape[0], _np(prim_idx), prim_idx.shape[0])
+    if rc:
+        raise MrtError(rc, "mrt_bvh2_save")
+
+
+def bvh2_load(path: str, n_tris: int):
+    """Load a BVH saved for exactly n_tris triangles (BVH::Load, tiny_bvh.h:1770-1799); MrtError(ERR_BAD_BVH)
+    if the file is for another triangle count, another version, or damaged."""
+    nodes = np.zeros(2 * n_tris, dtype=T.NODE32)
+    prim_idx = np.zeros(n_tris, dtype=np.uint32)
+    used = C.c_uint32(0)
+    rc = load().mrt_bvh2_load(os.fsencode(path), n_tris, _np(nodes), _np(prim_idx), C.byref(used))
+    if rc:
+        raise MrtError(rc, "mrt_bvh2_load")
     return nodes[:used.value].copy(), prim_idx, used.value
 
 
@@ -237,6 +263,19 @@ class Context:
         assert instances.dtype == T.INSTANCE
         self._chk(self.L.mrt_build_instanced_scene_device(self.h, _ptr(verts9), n_mesh_tris, _np(instances), instances.shape[0],
                                                           BUILD_TRIS_ON_DEVICE if on_device else 0))
+
+    def upload_two_level_scene(self, verts9, instances):
+        """SceneTLAS::build_tlas: one BLAS per distinct mesh, a TLAS over the instances (nothing is flattened)."""
+        verts9 = np.ascontiguousarray(verts9, dtype=np.float32)
+        instances = np.ascontiguousarray(instances)
+        assert instances.dtype == T.INSTANCE
+        self._chk(self.L.mrt_upload_two_level_scene(self.h, _np(verts9), verts9.size // 9, _np(instances), instances.shape[0]))
+
+    def update_instances(self, instances):
+        """SceneTLAS::refit_tlas: the same instances with new transforms."""
+        instances = np.ascontiguousarray(instances)
+        assert instances.dtype == T.INSTANCE
+        self._chk(self.L.mrt_update_instances(self.h, _np(instances), instances.shape[0]))
 
     def upload_scene(self, tris, nodes, prim_idx):
         tris = np.ascontiguousarray(tris)
@@ -355,3 +394,19 @@ class Scene:
 
     def upload(self, ctx: Context):
         ctx.upload_scene(self.tris, self.nodes, self.prim_idx)
+
+    def save_bvh(self, path: str) -> None:
+        bvh2_save(path, self.nodes, self.prim_idx)
+
+    @classmethod
+    def with_cached_bvh(cls, verts9, path: str, ids=None, layers=None, n_threads: int = 0):
+        """The scene with its BVH taken from the cache file if it fits, else built (and saved)."""
+        self = cls.__new__(cls)
+        self.tris = make_triangles(verts9, ids, layers)
+        self.verts4 = T.verts4_from_verts9(verts9)
+        try:
+            self.nodes, self.prim_idx, self.used_nodes = bvh2_load(path, self.tris.shape[0])
+        except MrtError:
+            self.nodes, self.prim_idx, self.used_nodes = bvh2_build(self.verts4, n_threads)
+            bvh2_save(path, self.nodes, self.prim_idx)
+        return self

@@ -51,6 +51,9 @@ struct mrt_ctx {
 	mrt::Dev4Node *d_nodes4 = nullptr; uint32_t n_nodes4 = 0;
 	mrt::Dev8Node *d_nodes8 = nullptr; uint32_t n_nodes8 = 0, stack8 = 0;
 	float *d_leaf_box = nullptr; // exact leaf boxes that go with d_nodes8
+	// two-level scene: d_nodes = TLAS + every BLAS, d_hot / d_cold = mesh-space triangles, d_instances in TLAS leaf order
+	mrt::DevInstance *d_instances = nullptr;
+	mrt::TwoLevelHost *two_level = nullptr; // host copy kept for mrt_update_instances
 	float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
 	uint32_t n_nodes = 0, n_tris = 0, depth = 0, stack_depth = 0, stack4 = 0;
 	bool scene = false;
@@ -109,6 +112,9 @@ void free_scene(mrt_ctx *ctx)
 	if (ctx->d_nodes8) (void)hipFree(ctx->d_nodes8);
 	if (ctx->d_leaf_box) (void)hipFree(ctx->d_leaf_box);
 	ctx->d_leaf_box = nullptr;
+	if (ctx->d_instances) (void)hipFree(ctx->d_instances);
+	ctx->d_instances = nullptr;
+	if (ctx->two_level) { mrt::free_two_level(ctx->two_level); delete ctx->two_level; ctx->two_level = nullptr; }
 	ctx->d_nodes = nullptr; ctx->d_hot = nullptr; ctx->d_cold = nullptr; ctx->d_nodes4 = nullptr; ctx->d_nodes8 = nullptr;
 	ctx->n_nodes8 = ctx->stack8 = 0;
 	ctx->scene = false; ctx->n_nodes = ctx->n_tris = 0;
@@ -132,7 +138,7 @@ uint32_t out_format(uint32_t flags, int mode)
 void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 {
 	std::memset(&p, 0, sizeof(p));
-	p.nodes = ctx->d_nodes; p.nodes4 = ctx->d_nodes4; p.nodes8 = ctx->d_nodes8; p.leaf_box = ctx->d_leaf_box; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold;
+	p.nodes = ctx->d_nodes; p.nodes4 = ctx->d_nodes4; p.nodes8 = ctx->d_nodes8; p.leaf_box = ctx->d_leaf_box; p.instances = ctx->d_instances; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold;
 	p.stack_depth = ctx->stack_depth; p.n_tris = ctx->n_tris;
 	if (ctx->opts.stack_override >= ctx->depth && ctx->opts.stack_override <= 64) p.stack_depth = ctx->opts.stack_override;
 	p.counters = ctx->d_counters;
@@ -146,6 +152,7 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 // primary-ray grids), one lane per ray for everything else (sorted / incoherent batches).
 uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent)
 {
+	if (ctx->two_level) return mrt::MRT_KERNEL_TWO_LEVEL; // a two-level scene has one kernel
 	// the 4-wide and the dual packet walks are retired (slower than the plain packet loop, and not
 	// exact for rays that lie in a box face): their ids run the packet kernel
 	if (ctx->opts.kernel == MRT_KERNEL_PACKET4 || ctx->opts.kernel == MRT_KERNEL_PACKET2) return MRT_KERNEL_PACKET;
@@ -228,6 +235,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	if (mode != MRT_MODE_NEAREST && mode != MRT_MODE_ANY_HIT) return fail(ctx, MRT_ERR_INVALID, "bad mode");
 	if ((flags & MRT_FLAG_BOOL_OUT) && mode != MRT_MODE_ANY_HIT) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT needs any-hit mode");
 	if ((flags & MRT_FLAG_BOOL_OUT) && (flags & MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT and TOKEN_OUT exclude each other");
+	if (ctx->two_level && (flags & MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_UNSUPPORTED, "hit tokens need a flat scene");
 	const size_t rs = ray_stride(flags), hs = hit_stride(flags, mode);
 	int rc;
 	const void *d_rays = rays;
@@ -264,7 +272,8 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	// Timed with the sort as pre-processing (last_sort_ms); last_trace_ms is the trace kernel alone.
 	const bool persistent_kind = p.kernel == MRT_KERNEL_LANE_PERSISTENT || p.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
 			p.kernel == MRT_KERNEL_LANE8_PERSISTENT;
-	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 4096 && ctx->opts.grid_tile != 1 && !persistent_kind;
+	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 4096 && ctx->opts.grid_tile != 1 && !persistent_kind &&
+			!ctx->two_level;
 	if (detect) {
 		uint32_t *d_auto = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);
 		HIP_TRY(ctx, mrt::launch_detect_grid(d_rays, p.in_fmt, count, p.tile_w_log2, ctx->d_counters + 16, d_auto, ctx->stream));
@@ -637,6 +646,76 @@ int mrt_build_instanced_scene_device(mrt_ctx *ctx, const float *verts9, uint32_t
 	return rc;
 }
 
+// SceneTLAS::build_tlas + every MeshBLAS::build (scene_tlas.h:140-176, mesh_blas.h:86-138): nothing is flattened
+int mrt_upload_two_level_scene(mrt_ctx *ctx, const float *verts9, uint32_t n_mesh_tris, const mrt_instance *instances,
+		uint32_t n_instances)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	if (!verts9 || !instances || n_instances == 0 || n_mesh_tris == 0) return fail(ctx, MRT_ERR_INVALID, "two-level scene: null or empty argument");
+	int rc = drain_pending(ctx);
+	if (rc) return rc;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	mrt::TwoLevelHost *h = new (std::nothrow) mrt::TwoLevelHost();
+	if (!h) return fail(ctx, MRT_ERR_OOM, "two-level scene: out of host memory");
+	unsigned n_thr = std::thread::hardware_concurrency();
+	rc = mrt::prepare_two_level(verts9, n_mesh_tris, instances, n_instances, n_thr ? n_thr : 1u, h, ctx->err, sizeof(ctx->err));
+	if (rc) { delete h; return rc; }
+	if (h->depth > 64u) { mrt::free_two_level(h); delete h; return fail(ctx, MRT_ERR_UNSUPPORTED, "two-level scene: trees too deep for the per-lane stack"); }
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	free_scene(ctx);
+	hipError_t e;
+	if ((e = hipMalloc(&ctx->d_nodes, (size_t)h->n_nodes * sizeof(mrt::DevNode))) != hipSuccess ||
+			(e = hipMalloc(&ctx->d_hot, (size_t)h->n_tris * sizeof(mrt::TriHot) + 16)) != hipSuccess ||
+			(e = hipMalloc(&ctx->d_cold, (size_t)h->n_tris * sizeof(mrt::TriCold))) != hipSuccess ||
+			(e = hipMalloc(&ctx->d_instances, (size_t)h->n_inst * sizeof(mrt::DevInstance))) != hipSuccess) {
+		mrt::free_two_level(h); delete h; free_scene(ctx);
+		return fail(ctx, MRT_ERR_OOM, "scene does not fit in device memory");
+	}
+	e = hipMemcpy(ctx->d_nodes, h->nodes, (size_t)h->n_nodes * sizeof(mrt::DevNode), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(ctx->d_hot, h->hot, (size_t)h->n_tris * sizeof(mrt::TriHot), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(ctx->d_cold, h->cold, (size_t)h->n_tris * sizeof(mrt::TriCold), hipMemcpyHostToDevice);
+	if (e == hipSuccess) e = hipMemcpy(ctx->d_instances, h->inst, (size_t)h->n_inst * sizeof(mrt::DevInstance), hipMemcpyHostToDevice);
+	if (e != hipSuccess) { mrt::free_two_level(h); delete h; free_scene(ctx); return fail(ctx, MRT_ERR_HIP, hipGetErrorString(e)); }
+	std::free(h->hot); std::free(h->cold); h->hot = nullptr; h->cold = nullptr; // the device has them; a refit only needs nodes + instances
+	ctx->two_level = h;
+	ctx->n_nodes = h->n_nodes; ctx->n_tris = h->n_tris; ctx->depth = h->depth;
+	ctx->stack_depth = ((h->depth + 7u) / 8u) * 8u;
+	if (ctx->stack_depth < 8) ctx->stack_depth = 8;
+	ctx->n_nodes4 = 0; ctx->stack4 = 0;
+	// sort keys (origin Morton) are quantised on the scene box: the union of the TLAS root's children
+	for (int c = 0; c < 3; c++) {
+		ctx->bounds_lo[c] = std::fmin(h->nodes[0].lmin[c], h->nodes[0].rmin[c]);
+		ctx->bounds_hi[c] = std::fmax(h->nodes[0].lmax[c], h->nodes[0].rmax[c]);
+	}
+	ctx->scene = true;
+	return MRT_OK;
+}
+
+// SceneTLAS::set_instance_transform + refit_tlas (scene_tlas.h:118-134,178-196): instances moved, meshes unchanged
+int mrt_update_instances(mrt_ctx *ctx, const mrt_instance *instances, uint32_t n_instances)
+{
+	if (!ctx) return MRT_ERR_INVALID;
+	if (!ctx->scene || !ctx->two_level) return fail(ctx, MRT_ERR_NO_SCENE, "no two-level scene uploaded");
+	if (!instances) return fail(ctx, MRT_ERR_INVALID, "null instances");
+	int rc = drain_pending(ctx);
+	if (rc) return rc;
+	HIP_TRY(ctx, hipSetDevice(ctx->device));
+	mrt::TwoLevelHost *h = ctx->two_level;
+	if ((rc = mrt::refit_two_level(h, instances, n_instances, ctx->err, sizeof(ctx->err)))) return rc;
+	if (h->depth > 64u) return fail(ctx, MRT_ERR_UNSUPPORTED, "two-level scene: trees too deep for the per-lane stack");
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	HIP_TRY(ctx, hipMemcpy(ctx->d_nodes, h->nodes, (size_t)h->n_tlas_nodes * sizeof(mrt::DevNode), hipMemcpyHostToDevice));
+	HIP_TRY(ctx, hipMemcpy(ctx->d_instances, h->inst, (size_t)h->n_inst * sizeof(mrt::DevInstance), hipMemcpyHostToDevice));
+	ctx->depth = h->depth;
+	ctx->stack_depth = ((h->depth + 7u) / 8u) * 8u;
+	if (ctx->stack_depth < 8) ctx->stack_depth = 8;
+	for (int c = 0; c < 3; c++) {
+		ctx->bounds_lo[c] = std::fmin(h->nodes[0].lmin[c], h->nodes[0].rmin[c]);
+		ctx->bounds_hi[c] = std::fmax(h->nodes[0].lmax[c], h->nodes[0].rmax[c]);
+	}
+	return MRT_OK;
+}
+
 int mrt_is_available(const mrt_ctx *ctx) { return ctx && ctx->scene ? 1 : 0; }
 
 int mrt_scene_info(const mrt_ctx *ctx, uint32_t *n_tris, uint32_t *n_wide_nodes, uint32_t *bvh_depth)
@@ -739,6 +818,7 @@ int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t
 	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded");
 	if (ctx->pending) return fail(ctx, MRT_ERR_PENDING, "collect the pending dispatch first");
 	if (flags & MRT_FLAG_HOST_LAYOUT) return fail(ctx, MRT_ERR_UNSUPPORTED, "grid casts write packed hits");
+	if (ctx->two_level && (flags & MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_UNSUPPORTED, "hit tokens need a flat scene");
 	if ((flags & MRT_FLAG_BOOL_OUT) && (flags & MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT and TOKEN_OUT exclude each other");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	mrt::TraceParams p;
@@ -800,6 +880,7 @@ int mrt_expand_tokens(mrt_ctx *ctx, const void *d_rays, const uint32_t *d_tokens
 {
 	if (!ctx) return MRT_ERR_INVALID;
 	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded");
+	if (ctx->two_level) return fail(ctx, MRT_ERR_UNSUPPORTED, "hit tokens need a flat scene");
 	if (count == 0) return MRT_OK;
 	if (!d_rays || !d_tokens || !d_hits) return fail(ctx, MRT_ERR_INVALID, "null rays / tokens / hits");
 	if (flags & (MRT_FLAG_BOOL_OUT | MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_INVALID, "tokens expand to hit records only");
@@ -818,6 +899,7 @@ int mrt_expand_grid_tokens(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w,
 {
 	if (!ctx) return MRT_ERR_INVALID;
 	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded");
+	if (ctx->two_level) return fail(ctx, MRT_ERR_UNSUPPORTED, "hit tokens need a flat scene");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	mrt::TraceParams p;
 	int rc = grid_params(ctx, cam, grid_w, grid_h, y0, y1, p);

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -296,4 +297,59 @@ extern "C" int mrt_bvh2_build(const float *verts4, uint32_t n_tris, mrt_bvh_node
 	}
 	*used_nodes = 2 + 2 * next_rank;
 	return MRT_OK;
+}
+
+// ---- BVH cache file: the counterpart of tinybvh::BVH::Save / Load (tiny_bvh.h:1747-1799) -----------
+// Layout: 32-byte header {magic "MRTBVH2\0", version, n_tris, used_nodes, 64-bit FNV-1a of the payload},
+// then used_nodes nodes (32 B each) and n_tris prim indices.  Like the reference's Load, a file is
+// only accepted for the triangle count it was saved for; unlike it, the payload is checksummed and the
+// node and index ranges are validated by mrt_upload_scene, so a damaged file cannot reach the device.
+namespace {
+struct CacheHeader { char magic[8]; uint32_t version, n_tris, used_nodes, reserved; uint64_t checksum; };
+static_assert(sizeof(CacheHeader) == 32, "cache header must be 32 bytes");
+const char kCacheMagic[8] = { 'M', 'R', 'T', 'B', 'V', 'H', '2', 0 };
+constexpr uint32_t kCacheVersion = 1;
+uint64_t fnv1a(uint64_t h, const void *p, size_t n)
+{
+	const unsigned char *b = (const unsigned char *)p;
+	for (size_t i = 0; i < n; i++) { h ^= b[i]; h *= 1099511628211ull; }
+	return h;
+}
+} // namespace
+
+extern "C" int mrt_bvh2_save(const char *path, const mrt_bvh_node32 *nodes, uint32_t used_nodes, const uint32_t *prim_idx, uint32_t n_tris)
+{
+	if (!path || !nodes || !prim_idx || used_nodes == 0 || n_tris == 0) return MRT_ERR_INVALID;
+	CacheHeader h;
+	std::memset(&h, 0, sizeof(h));
+	std::memcpy(h.magic, kCacheMagic, 8);
+	h.version = kCacheVersion; h.n_tris = n_tris; h.used_nodes = used_nodes;
+	h.checksum = fnv1a(fnv1a(14695981039346656037ull, nodes, (size_t)used_nodes * sizeof(mrt_bvh_node32)), prim_idx, (size_t)n_tris * 4);
+	std::FILE *f = std::fopen(path, "wb");
+	if (!f) return MRT_ERR_INVALID;
+	bool ok = std::fwrite(&h, sizeof(h), 1, f) == 1 &&
+			std::fwrite(nodes, sizeof(mrt_bvh_node32), used_nodes, f) == used_nodes &&
+			std::fwrite(prim_idx, 4, n_tris, f) == n_tris;
+	ok = (std::fclose(f) == 0) && ok;
+	return ok ? MRT_OK : MRT_ERR_INVALID;
+}
+
+extern "C" int mrt_bvh2_load(const char *path, uint32_t n_tris, mrt_bvh_node32 *nodes, uint32_t *prim_idx, uint32_t *used_nodes)
+{
+	if (!path || !nodes || !prim_idx || !used_nodes || n_tris == 0) return MRT_ERR_INVALID;
+	std::FILE *f = std::fopen(path, "rb");
+	if (!f) return MRT_ERR_INVALID;
+	CacheHeader h;
+	int rc = MRT_ERR_BAD_BVH;
+	if (std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, kCacheMagic, 8) == 0 && h.version == kCacheVersion &&
+			h.n_tris == n_tris && h.used_nodes >= 1 && (uint64_t)h.used_nodes <= 2ull * n_tris) { // the caller's array holds 2 n_tris nodes
+		if (std::fread(nodes, sizeof(mrt_bvh_node32), h.used_nodes, f) == h.used_nodes &&
+				std::fread(prim_idx, 4, n_tris, f) == n_tris && std::fgetc(f) == EOF &&
+				h.checksum == fnv1a(fnv1a(14695981039346656037ull, nodes, (size_t)h.used_nodes * sizeof(mrt_bvh_node32)), prim_idx, (size_t)n_tris * 4)) {
+			*used_nodes = h.used_nodes;
+			rc = MRT_OK;
+		}
+	}
+	std::fclose(f);
+	return rc;
 }

@@ -292,6 +292,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 #include "lane_persistent_kernel.h"
 #include "packet_kernel.h"
 #include "packet_asm_kernel.h"
+#include "two_level_kernel.h"
 
 // ---- standalone ray generation (mrt_generate_grid) ---------------------------------
 __global__ __launch_bounds__(MRT_WG) void grid_rays_kernel(const TraceParams p, mrt_ray32 *out)
@@ -531,6 +532,12 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 	const uint64_t blocks = (threads + MRT_WG - 1) / MRT_WG;
 	if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
 	dim3 grid((uint32_t)blocks), wg(MRT_WG);
+	if (p.kernel == MRT_KERNEL_TWO_LEVEL) { // two-level scene: one lane per ray, per-lane LDS stack
+		const size_t lds2 = (size_t)(MRT_WG / MRT_WAVE) * p.stack_depth * MRT_WAVE * sizeof(uint32_t);
+		if (any_hit) hipLaunchKernelGGL((trace_two_level_kernel<true>), grid, wg, lds2, stream, p);
+		else hipLaunchKernelGGL((trace_two_level_kernel<false>), grid, wg, lds2, stream, p);
+		return hipGetLastError();
+	}
 	if (p.kernel == MRT_KERNEL_PACKET_ASM && !count) { // counting builds use the C++ packet kernel
 		if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true>), grid, wg, 0, stream, p);
 		else hipLaunchKernelGGL((trace_packet_asm_kernel<false>), grid, wg, 0, stream, p);

@@ -85,11 +85,13 @@ enum InFmt : uint32_t { IN_RAY32 = 0, IN_HOST60 = 1, IN_GRID = 2 };
 enum OutFmt : uint32_t { OUT_HIT32 = 0, OUT_HOST44 = 1, OUT_BOOL8 = 2, OUT_TOKEN4 = 3 };
 enum LaneMap : uint32_t { MAP_LINEAR = 0, MAP_TILE8X8 = 1, MAP_AUTO = 2 };
 
+struct DevInstance;
 struct TraceParams {
 	const DevNode *nodes;
 	const Dev4Node *nodes4;    // packet kernel, 4-wide layout (may be null)
 	const Dev8Node *nodes8;    // 8-wide compressed layout (may be null)
 	const float *leaf_box;     // with nodes8: exact box {min xyz, -, max xyz, -} of the leaf that starts at a slot
+	const DevInstance *instances; // two-level scenes (kernel == MRT_KERNEL_TWO_LEVEL)
 	const TriHot *tri_hot;
 	const TriCold *tri_cold;
 	const void *rays;          // IN_RAY32 / IN_HOST60 (device)
@@ -141,5 +143,41 @@ struct DeviceBuildResult {
 };
 int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want8, bool safe_handoff, void *stream,
 		DeviceBuildResult *out, char *err, size_t err_len);
+
+// ---- two-level scene: SceneTLAS / MeshBLAS / BLASInstance
+// (src/accel/scene_tlas.h:140-251, mesh_blas.h:86-138, blas_instance.h:47-107) -------------
+// One node array: TLAS nodes at [0, tlas_cap) (rebuilt in place when instances move), the BLAS
+// of every distinct mesh behind them, node and leaf refs already global.  A TLAS leaf ref is the
+// first slot of a run of DevInstance rows (leaf order; the last row of a leaf has flags & 1).
+constexpr uint32_t kInstanceReturn = 0x7FFFFFFEu; // stack marker: back from a BLAS to the TLAS walk
+constexpr uint32_t MRT_KERNEL_TWO_LEVEL = 100u;    // internal kernel id (TraceParams.kernel)
+struct alignas(16) DevInstance {
+	float inv[12];      // world -> object, rows {m00 m01 m02 tx}: o' = M o + t, d' = M d (no renormalisation: t stays world-parameterised)
+	float basis[9];     // object -> world 3x3 (normals: normalize(basis n))
+	uint32_t root;      // BLAS root node (global index)
+	uint32_t id_base;   // flat id of the instance's first triangle (running offset in registration order)
+	uint32_t layers;    // the mesh's layer mask
+	uint32_t flags;     // 1 = last instance of its TLAS leaf
+	uint32_t index;     // registration index
+	uint32_t pad[6];
+};
+static_assert(sizeof(DevInstance) == 128, "DevInstance must be 128 bytes");
+
+struct TwoLevelBlas { uint32_t first_tri, n_tris, root, depth; float lo[3], hi[3]; };
+struct TwoLevelHost {
+	DevNode *nodes = nullptr; uint32_t n_nodes = 0, tlas_cap = 0, n_tlas_nodes = 0;
+	TriHot *hot = nullptr; TriCold *cold = nullptr; uint32_t n_tris = 0;   // all BLAS triangles, mesh-space
+	DevInstance *inst = nullptr; uint32_t n_inst = 0;
+	TwoLevelBlas *blas = nullptr; uint32_t n_blas = 0;
+	uint32_t *inst_blas = nullptr;   // per registered instance: its BLAS
+	uint32_t depth = 0;              // stack entries one ray can need
+	uint64_t flat_tris = 0;          // triangles of the flattened scene (sum over instances)
+};
+void free_two_level(TwoLevelHost *h);
+// Builds every BLAS (binned SAH, as MeshBLAS::build) and the TLAS over the instances' world boxes.
+int prepare_two_level(const float *verts9, uint32_t n_mesh_tris, const mrt_instance *instances, uint32_t n_instances,
+		uint32_t n_threads, TwoLevelHost *out, char *err, size_t err_len);
+// New transforms for the same instances: inverse, world box, TLAS rebuilt into nodes[0, tlas_cap) and inst[].
+int refit_two_level(TwoLevelHost *h, const mrt_instance *instances, uint32_t n_instances, char *err, size_t err_len);
 
 } // namespace mrt

@@ -628,3 +628,256 @@ void orc_flatten_instances(const float *verts9, const orc_instance *inst, uint32
 		}
 	}
 }
+
+/* ------------------------------------------------------------------------- */
+/* Two-level scene: SceneTLAS::build_tlas / cast_ray / any_hit                   */
+/* (src/accel/scene_tlas.h:140-251), MeshBLAS::build (mesh_blas.h:86-138),       */
+/* BLASInstance (blas_instance.h:47-107) and tinybvh::BVH::IntersectTLAS         */
+/* (thirdparty/tinybvh/tiny_bvh.h:3306-3380): a BVH per distinct mesh in mesh    */
+/* space, a BVH over the instances' world boxes; per TLAS leaf the ray is taken  */
+/* to mesh space by the inverse transform WITHOUT renormalising the direction    */
+/* (blas_instance.h:56-66, tiny_bvh.h:3327-3331), so t, t_min and the best hit   */
+/* stay world-parameterised.  Box and triangle tests are the ones above.         */
+/* Deliberate differences from the reference, shared with the HIP path:          */
+/*  - prim_id is the FLAT id of raytracer_server.cpp:700-711 (running triangle   */
+/*    offset of the instance + mesh-local index); SceneTLAS reports the local    */
+/*    index, which its callers cannot resolve;      */
+/*  - hit_layers is the instance's mask (raytracer_server.cpp:702-703) and whole */
+/*    instances are skipped by the query mask (tiny_bvh.h:3323-3324);            */
+/*  - an exact tie in t goes to the lower flat id (as in trace_one);             */
+/*  - the inverse is taken in double and rounded once; a world box is the image  */
+/*    of the mesh box's corners (blas_instance.h:76-107) in double, rounded      */
+/*    outwards.                                                                  */
+/* ------------------------------------------------------------------------- */
+typedef struct { orc_wide64 *wide; orc_tri64 *lt; uint32_t n_wide, n_tris, first_tri; float lo[3], hi[3]; } tl_blas;
+typedef struct { float inv[12]; float basis[9]; uint32_t blas, id_base, layers; } tl_inst;
+struct orc_two_level {
+	tl_blas *blas; uint32_t n_blas;
+	tl_inst *inst; uint32_t n_inst;
+	orc_wide64 *tlas; orc_tri64 *tlas_lt; uint32_t n_tlas; /* tlas_lt[k].id = instance in leaf slot k */
+};
+
+static int build_wide(const float *verts9, uint32_t n, orc_wide64 **wide, uint32_t *n_wide, orc_tri64 **lt)
+{
+	orc_tri64 *tris = (orc_tri64 *)malloc((size_t)n * sizeof(orc_tri64));
+	float *v4 = (float *)malloc((size_t)n * 12 * sizeof(float));
+	orc_node32 *nodes = (orc_node32 *)malloc((size_t)2 * n * sizeof(orc_node32));
+	uint32_t *prim = (uint32_t *)malloc((size_t)n * sizeof(uint32_t));
+	*wide = (orc_wide64 *)malloc((size_t)2 * n * sizeof(orc_wide64));
+	*lt = (orc_tri64 *)malloc((size_t)n * sizeof(orc_tri64));
+	int rc = 1;
+	if (tris && v4 && nodes && prim && *wide && *lt) {
+		orc_make_triangles(verts9, 0, 0, n, tris);
+		for (size_t t = 0; t < (size_t)n * 3; t++) { v4[4 * t] = verts9[3 * t]; v4[4 * t + 1] = verts9[3 * t + 1]; v4[4 * t + 2] = verts9[3 * t + 2]; v4[4 * t + 3] = 0.0f; }
+		uint32_t used = 0;
+		rc = orc_bvh2_build(v4, n, nodes, prim, &used);
+		if (!rc) rc = orc_to_wide(tris, n, nodes, used, prim, *wide, n_wide, *lt);
+	}
+	free(tris); free(v4); free(nodes); free(prim);
+	return rc;
+}
+
+void orc_two_level_free(orc_two_level *s)
+{
+	if (!s) return;
+	for (uint32_t k = 0; k < s->n_blas; k++) { free(s->blas[k].wide); free(s->blas[k].lt); }
+	free(s->blas); free(s->inst); free(s->tlas); free(s->tlas_lt); free(s);
+}
+
+orc_two_level *orc_two_level_build(const float *verts9, uint32_t n_mesh_tris, const orc_instance *inst, uint32_t n_inst)
+{
+	if (!verts9 || !inst || n_inst == 0) return 0;
+	orc_two_level *s = (orc_two_level *)calloc(1, sizeof(*s));
+	if (!s) return 0;
+	s->blas = (tl_blas *)calloc(n_inst, sizeof(tl_blas));
+	s->inst = (tl_inst *)calloc(n_inst, sizeof(tl_inst));
+	float *boxes = (float *)malloc((size_t)n_inst * 9 * sizeof(float));
+	if (!s->blas || !s->inst || !boxes) { free(boxes); orc_two_level_free(s); return 0; }
+	s->n_inst = n_inst;
+	uint32_t id_base = 0;
+	for (uint32_t i = 0; i < n_inst; i++) {
+		const orc_instance *in = &inst[i];
+		if (in->n_tris == 0 || in->first_tri >= n_mesh_tris || in->n_tris > n_mesh_tris - in->first_tri) { free(boxes); orc_two_level_free(s); return 0; }
+		uint32_t b = 0;
+		while (b < s->n_blas && !(s->blas[b].first_tri == in->first_tri && s->blas[b].n_tris == in->n_tris)) b++;
+		if (b == s->n_blas) { /* MeshBLAS::build, mesh_blas.h:86-138 */
+			tl_blas *nb = &s->blas[s->n_blas];
+			nb->first_tri = in->first_tri; nb->n_tris = in->n_tris;
+			if (build_wide(verts9 + 9 * (size_t)in->first_tri, in->n_tris, &nb->wide, &nb->n_wide, &nb->lt)) { s->n_blas++; free(boxes); orc_two_level_free(s); return 0; }
+			for (int c = 0; c < 3; c++) { /* mesh box = union of the root's child boxes */
+				nb->lo[c] = fminf(nb->wide[0].lmin[c], nb->wide[0].rmin[c]);
+				nb->hi[c] = fmaxf(nb->wide[0].lmax[c], nb->wide[0].rmax[c]);
+			}
+			s->n_blas++;
+		}
+		tl_inst *d = &s->inst[i];
+		d->blas = b; d->id_base = id_base; d->layers = in->layers;
+		id_base += in->n_tris;
+		/* Transform3D::affine_inverse (blas_instance.h:43-45), cofactors in double */
+		const double a = in->basis[0], bb = in->basis[1], c = in->basis[2], dd = in->basis[3], e = in->basis[4], f = in->basis[5],
+				g = in->basis[6], h = in->basis[7], ii = in->basis[8];
+		const double c00 = e * ii - f * h, c01 = c * h - bb * ii, c02 = bb * f - c * e;
+		const double c10 = f * g - dd * ii, c11 = a * ii - c * g, c12 = c * dd - a * f;
+		const double c20 = dd * h - e * g, c21 = bb * g - a * h, c22 = a * e - bb * dd;
+		const double det = a * c00 + bb * c10 + c * c20;
+		if (!(fabs(det) > 0.0)) { free(boxes); orc_two_level_free(s); return 0; }
+		const double m[9] = { c00 / det, c01 / det, c02 / det, c10 / det, c11 / det, c12 / det, c20 / det, c21 / det, c22 / det };
+		for (int r = 0; r < 3; r++) {
+			const double t = -(m[3 * r] * (double)in->origin[0] + m[3 * r + 1] * (double)in->origin[1] + m[3 * r + 2] * (double)in->origin[2]);
+			d->inv[4 * r] = (float)m[3 * r]; d->inv[4 * r + 1] = (float)m[3 * r + 1]; d->inv[4 * r + 2] = (float)m[3 * r + 2]; d->inv[4 * r + 3] = (float)t;
+		}
+		for (int k = 0; k < 9; k++) d->basis[k] = in->basis[k];
+		/* BLASInstance::compute_world_bounds, blas_instance.h:76-107 (double, rounded outwards) */
+		const tl_blas *mb = &s->blas[b];
+		double mn[3] = { INFINITY, INFINITY, INFINITY }, mx[3] = { -INFINITY, -INFINITY, -INFINITY };
+		for (int k = 0; k < 8; k++) {
+			const double x = (k & 1) ? mb->hi[0] : mb->lo[0], y = (k & 2) ? mb->hi[1] : mb->lo[1], z = (k & 4) ? mb->hi[2] : mb->lo[2];
+			for (int r = 0; r < 3; r++) {
+				const double w = ((double)in->basis[3 * r] * x + (double)in->basis[3 * r + 1] * y) + (double)in->basis[3 * r + 2] * z + (double)in->origin[r];
+				if (w < mn[r]) mn[r] = w;
+				if (w > mx[r]) mx[r] = w;
+			}
+		}
+		for (int r = 0; r < 3; r++) { /* proxy triangle {lo, hi, centre}: its AABB is the box */
+			float l = (float)mn[r], u = (float)mx[r];
+			if ((double)l > mn[r]) l = nextafterf(l, -INFINITY);
+			if ((double)u < mx[r]) u = nextafterf(u, INFINITY);
+			boxes[9 * (size_t)i + r] = l; boxes[9 * (size_t)i + 3 + r] = u; boxes[9 * (size_t)i + 6 + r] = 0.5f * l + 0.5f * u;
+		}
+	}
+	/* SceneTLAS::build_tlas, scene_tlas.h:140-176: the same builder over the instance boxes */
+	const int rc = build_wide(boxes, n_inst, &s->tlas, &s->n_tlas, &s->tlas_lt);
+	free(boxes);
+	if (rc) { orc_two_level_free(s); return 0; }
+	return s;
+}
+
+/* BVH::Intersect of one BLAS with the mesh-space ray: trace_one's loop on shared best-hit state */
+static int walk_blas(const tl_blas *b, const float o[3], const float d[3], float t_min, uint32_t id_base, int any_hit,
+		float *best_t, float *best_u, float *best_v, int64_t *best_slot, uint32_t *best_id)
+{
+	const float inv[3] = { safe_inv(d[0]), safe_inv(d[1]), safe_inv(d[2]) };
+	const float nro[3] = { -(o[0] * inv[0]), -(o[1] * inv[1]), -(o[2] * inv[2]) };
+	stack_ent stack[256];
+	uint32_t sp = 0;
+	int found = 0;
+	stack[sp].node = 0; stack[sp].tmin = -1e30f; sp++;
+	while (sp > 0) {
+		sp--;
+		const uint32_t ni = stack[sp].node;
+		if (stack[sp].tmin > *best_t) continue;
+		const orc_wide64 *n = &b->wide[ni];
+		float tl, tr;
+		int hl = slab(n->lmin, n->lmax, inv, nro, t_min, *best_t, &tl) && tl <= *best_t;
+		int hr = slab(n->rmin, n->rmax, inv, nro, t_min, *best_t, &tr) && tr <= *best_t;
+		for (int side = 0; side < 2; side++) {
+			const int h = side ? hr : hl;
+			const uint32_t cnt = side ? n->right_count : n->left_count, first = side ? n->right_idx : n->left_idx;
+			if (!(h && cnt > 0)) continue;
+			for (uint32_t k = 0; k < cnt; k++) {
+				orc_tri64 tri = b->lt[first + k];
+				tri.id += id_base; /* flat id: the tie rule compares these */
+				float t, u, v;
+				if (tri_hit(&tri, o, d, t_min, *best_t, *best_slot >= 0, *best_id, &t, &u, &v)) {
+					*best_t = t; *best_u = u; *best_v = v; *best_slot = (int64_t)(first + k); *best_id = tri.id;
+					found = 1;
+					if (any_hit) return 1;
+				}
+			}
+		}
+		const int pl = hl && n->left_count == 0, pr = hr && n->right_count == 0;
+		if (pl && pr) {
+			if (tl < tr) {
+				stack[sp].node = n->right_idx; stack[sp].tmin = tr; sp++;
+				stack[sp].node = n->left_idx; stack[sp].tmin = tl; sp++;
+			} else {
+				stack[sp].node = n->left_idx; stack[sp].tmin = tl; sp++;
+				stack[sp].node = n->right_idx; stack[sp].tmin = tr; sp++;
+			}
+		} else if (pl) { stack[sp].node = n->left_idx; stack[sp].tmin = tl; sp++; }
+		else if (pr) { stack[sp].node = n->right_idx; stack[sp].tmin = tr; sp++; }
+	}
+	return found;
+}
+
+static void two_level_one(const orc_two_level *s, const orc_ray32 *ray, orc_hit32 *out, uint32_t mask, int any_hit)
+{
+	const float *o = ray->origin, *d = ray->direction;
+	const float t_min = ray->t_min, t_max = ray->t_max;
+	if (t_min >= t_max) { write_miss(out, t_max); return; }
+	const float inv[3] = { safe_inv(d[0]), safe_inv(d[1]), safe_inv(d[2]) };
+	const float nro[3] = { -(o[0] * inv[0]), -(o[1] * inv[1]), -(o[2] * inv[2]) };
+	float best_t = t_max, best_u = 0.0f, best_v = 0.0f;
+	int64_t best_slot = -1; uint32_t best_id = 0xFFFFFFFFu, best_inst = 0;
+	stack_ent stack[256];
+	uint32_t sp = 0;
+	stack[sp].node = 0; stack[sp].tmin = -1e30f; sp++;
+	while (sp > 0) { /* tiny_bvh.h:3314-3378 */
+		sp--;
+		const uint32_t ni = stack[sp].node;
+		if (stack[sp].tmin > best_t) continue;
+		const orc_wide64 *n = &s->tlas[ni];
+		float tl, tr;
+		int hl = slab(n->lmin, n->lmax, inv, nro, t_min, best_t, &tl) && tl <= best_t;
+		int hr = slab(n->rmin, n->rmax, inv, nro, t_min, best_t, &tr) && tr <= best_t;
+		for (int side = 0; side < 2; side++) {
+			const int h = side ? hr : hl;
+			const uint32_t cnt = side ? n->right_count : n->left_count, first = side ? n->right_idx : n->left_idx;
+			if (!(h && cnt > 0)) continue;
+			for (uint32_t k = 0; k < cnt; k++) { /* tiny_bvh.h:3320-3360 */
+				const uint32_t ii = s->tlas_lt[first + k].id;
+				const tl_inst *in = &s->inst[ii];
+				if ((in->layers & mask) == 0u) continue;
+				const float *m = in->inv;
+				const float oo[3] = { fmaf(m[0], o[0], fmaf(m[1], o[1], fmaf(m[2], o[2], m[3]))),
+						fmaf(m[4], o[0], fmaf(m[5], o[1], fmaf(m[6], o[2], m[7]))),
+						fmaf(m[8], o[0], fmaf(m[9], o[1], fmaf(m[10], o[2], m[11]))) };
+				const float od[3] = { fmaf(m[0], d[0], fmaf(m[1], d[1], m[2] * d[2])),
+						fmaf(m[4], d[0], fmaf(m[5], d[1], m[6] * d[2])),
+						fmaf(m[8], d[0], fmaf(m[9], d[1], m[10] * d[2])) };
+				const float before_t = best_t; const uint32_t before_id = best_id;
+				if (walk_blas(&s->blas[in->blas], oo, od, t_min, in->id_base, any_hit, &best_t, &best_u, &best_v, &best_slot, &best_id)) {
+					if (best_t != before_t || best_id != before_id) best_inst = ii;
+					if (any_hit) goto done;
+				}
+			}
+		}
+		const int pl = hl && n->left_count == 0, pr = hr && n->right_count == 0;
+		if (pl && pr) {
+			if (tl < tr) {
+				stack[sp].node = n->right_idx; stack[sp].tmin = tr; sp++;
+				stack[sp].node = n->left_idx; stack[sp].tmin = tl; sp++;
+			} else {
+				stack[sp].node = n->left_idx; stack[sp].tmin = tl; sp++;
+				stack[sp].node = n->right_idx; stack[sp].tmin = tr; sp++;
+			}
+		} else if (pl) { stack[sp].node = n->left_idx; stack[sp].tmin = tl; sp++; }
+		else if (pr) { stack[sp].node = n->right_idx; stack[sp].tmin = tr; sp++; }
+	}
+done:
+	if (best_slot >= 0) { /* scene_tlas.h:217-244 */
+		const tl_inst *in = &s->inst[best_inst];
+		const orc_tri64 *tri = &s->blas[in->blas].lt[best_slot];
+		const float *b = in->basis, *no = tri->normal;
+		float nx = fmaf(b[0], no[0], fmaf(b[1], no[1], b[2] * no[2]));
+		float ny = fmaf(b[3], no[0], fmaf(b[4], no[1], b[5] * no[2]));
+		float nz = fmaf(b[6], no[0], fmaf(b[7], no[1], b[8] * no[2]));
+		const float l2 = fmaf(nx, nx, fmaf(ny, ny, nz * nz));
+		if (l2 == 0.0f) { nx = ny = nz = 0.0f; }
+		else { const float l = sqrtf(l2); nx /= l; ny /= l; nz /= l; }
+		out->t = best_t; out->prim_id = (int32_t)best_id; out->bary_u = best_u; out->bary_v = best_v;
+		out->normal[0] = nx; out->normal[1] = ny; out->normal[2] = nz;
+		out->hit_layers = in->layers;
+	} else write_miss(out, best_t);
+}
+
+void orc_two_level_trace(const orc_two_level *s, const orc_ray32 *rays, orc_hit32 *hits, uint64_t count,
+		uint32_t query_mask, int any_hit, int n_threads)
+{
+#ifdef _OPENMP
+	if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 256)
+#endif
+	for (int64_t i = 0; i < (int64_t)count; i++) two_level_one(s, &rays[i], &hits[i], query_mask, any_hit);
+	(void)n_threads;
+}

@@ -54,6 +54,14 @@ void orc_trace(const orc_wide64 *wide, const orc_tri64 *leaf_tris, const orc_ray
 /* src/accel/ray_scene.h:120-131,151-162 with the acceptance rules of triangle.h:56-105 / glsl:105-131 */
 void orc_trace_brute(const orc_tri64 *tris, uint32_t n_tris, const orc_ray32 *rays, orc_hit32 *hits,
 		uint64_t count, uint32_t query_mask, int any_hit, int n_threads);
+/* Two-level scene: src/accel/scene_tlas.h:140-251 (build_tlas, cast_ray, any_hit), mesh_blas.h:86-138,
+ * blas_instance.h:47-107, tinybvh IntersectTLAS tiny_bvh.h:3306-3380.  prim_id = flat id
+ * (raytracer_server.cpp:700-711), hit_layers = the instance's mask; see the comment in the .c file. */
+typedef struct orc_two_level orc_two_level;
+orc_two_level *orc_two_level_build(const float *verts9, uint32_t n_mesh_tris, const orc_instance *inst, uint32_t n_inst);
+void orc_two_level_free(orc_two_level *s);
+void orc_two_level_trace(const orc_two_level *s, const orc_ray32 *rays, orc_hit32 *hits, uint64_t count,
+		uint32_t query_mask, int any_hit, int n_threads);
 /* Single ray vs single triangle; returns 1 and t/u/v when accepted with best_t = ray.t_max */
 int orc_tri_test(const orc_tri64 *tri, const orc_ray32 *ray, float *t, float *u, float *v);
 /* src/godot/raytracer_debug.cpp:572-596 */

@@ -55,6 +55,8 @@ def lib():
         L.orc_to_wide.restype = C.c_int
         L.orc_tri_test.restype = C.c_int
         L.orc_morton_key.restype = C.c_uint32
+        L.orc_two_level_build.restype = C.c_void_p
+        L.orc_two_level_free.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -207,6 +209,32 @@ class OracleScene:
 
     def brute(self, rays, **kw):
         return trace_brute(self.tris, rays, **kw)
+
+
+class OracleTwoLevelScene:
+    """SceneTLAS of the reference (src/accel/scene_tlas.h:140-251): one BVH per distinct mesh in mesh
+    space, one over the instances; rays go to mesh space per instance (mrt_oracle.c, two-level section)."""
+
+    def __init__(self, verts9, instances):
+        v = np.ascontiguousarray(verts9, dtype=np.float32).reshape(-1, 9)
+        inst = np.ascontiguousarray(instances)
+        assert inst.dtype.itemsize == 64
+        self.h = lib().orc_two_level_build(_p(v), C.c_uint32(v.shape[0]), _p(inst), C.c_uint32(inst.shape[0]))
+        if not self.h:
+            raise ValueError("orc_two_level_build failed (bad range or singular transform)")
+
+    def trace(self, rays, query_mask=0xFFFFFFFF, any_hit=False, threads=0):
+        rays = np.ascontiguousarray(rays)
+        assert rays.dtype.itemsize == 32
+        hits = np.zeros(rays.shape[0], dtype=HIT32)
+        lib().orc_two_level_trace(C.c_void_p(self.h), _p(rays), _p(hits), C.c_uint64(rays.shape[0]), C.c_uint32(query_mask),
+                                  C.c_int(1 if any_hit else 0), C.c_int(threads))
+        return hits
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().orc_two_level_free(C.c_void_p(self.h))
+            self.h = None
 
 
 # ---------------------------------------------------------------------------

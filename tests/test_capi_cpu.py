@@ -47,6 +47,8 @@ def test_null_arguments_are_rejected_not_crashed(built):
     assert L.mrt_flatten_instances(None, None, 0, None, 0, 0, None) == capi.ERR_INVALID
     assert L.mrt_build_instanced_scene_device(None, None, 0, None, 0, 0) == capi.ERR_INVALID
     assert L.mrt_expand_tokens(None, None, None, None, 0, 0, None) == capi.ERR_INVALID
+    assert L.mrt_upload_two_level_scene(None, None, 0, None, 0) == capi.ERR_INVALID
+    assert L.mrt_update_instances(None, None, 0) == capi.ERR_INVALID
     assert L.mrt_expand_grid_tokens(None, None, 0, 0, 0, 0, None, None, None) == capi.ERR_INVALID
     assert C.sizeof(capi.Stats) == 80 and T.INSTANCE.itemsize == 64
     L.mrt_destroy(None)  # no-op
@@ -138,3 +140,35 @@ def test_instances_flatten_to_the_multi_mesh_scene():
     assert flat.tobytes() == want.tobytes()
     assert capi.make_triangles(world, np.arange(1500, dtype=np.uint32),
                                np.repeat(inst["layers"], inst["n_tris"]).astype(np.uint32)).tobytes() == want.tobytes()
+
+
+def test_bvh_cache_file_round_trip(built, tmp_path):
+    """mrt_bvh2_save / mrt_bvh2_load (BVH::Save / Load, tiny_bvh.h:1747-1799): the loaded tree is the saved one;
+    a file for another triangle count, a truncated or a damaged file is refused."""
+    v = synth.soup(3000, 0.3, 5)
+    v4 = T.verts4_from_verts9(v)
+    nodes, prim, used = capi.bvh2_build(v4, 2)
+    path = str(tmp_path / "scene.bvh")
+    capi.bvh2_save(path, nodes, prim)
+    n2, p2, u2 = capi.bvh2_load(path, 3000)
+    assert u2 == used and n2.tobytes() == nodes.tobytes() and np.array_equal(p2, prim)
+    with pytest.raises(capi.MrtError) as e:
+        capi.bvh2_load(path, 2999)                      # saved for another scene
+    assert e.value.status == capi.ERR_BAD_BVH
+    raw = bytearray(open(path, "rb").read())
+    assert len(raw) == 32 + used * 32 + 3000 * 4
+    open(path, "wb").write(raw[:-4])                    # truncated
+    with pytest.raises(capi.MrtError):
+        capi.bvh2_load(path, 3000)
+    raw[100] ^= 0x40                                    # one flipped bit in a node
+    open(path, "wb").write(raw)
+    with pytest.raises(capi.MrtError):
+        capi.bvh2_load(path, 3000)
+    with pytest.raises(capi.MrtError):
+        capi.bvh2_load(str(tmp_path / "missing.bvh"), 3000)
+    # Scene.with_cached_bvh builds and saves on a miss, loads on a hit
+    a = capi.Scene.with_cached_bvh(v, path)
+    b = capi.Scene.with_cached_bvh(v, path)
+    assert a.nodes.tobytes() == b.nodes.tobytes() == nodes.tobytes() and np.array_equal(b.prim_idx, prim)
+    assert capi.load().mrt_bvh2_save(None, None, 0, None, 0) == capi.ERR_INVALID
+    assert capi.load().mrt_bvh2_load(None, 0, None, None, None) == capi.ERR_INVALID

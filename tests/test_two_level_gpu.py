@@ -1,0 +1,152 @@
+"""mrt_upload_two_level_scene / mrt_update_instances: the two-level walk on the device (TLAS over
+instances, one BLAS per distinct mesh, rays taken to mesh space per instance) against the oracle's
+restatement of SceneTLAS (oracle/mrt_oracle.c, two-level section) -- same arithmetic, so bit-exact --
+and, with the two-level tolerance, against the flattened scene walked by the flat kernels."""
+import numpy as np
+import pytest
+
+from messyerraytracer_amd import capi, synth, types as T
+from oracle import pyoracle as po
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(n_meshes=8, tris=3000, scale=0.25, seed=7):
+    local, inst = synth.multi_mesh_instances(n_meshes, tris, scale, seed)
+    extra = inst[[0, 3]].copy()                       # meshes 0 and 3 placed a second time
+    extra["origin"] += np.float32([0.5, -0.25, 1.0])
+    extra["layers"] = [0x2, 0x4]
+    return local, np.concatenate([inst, extra])
+
+
+def _rays():
+    grid = po.grid_rays((0, 0, -12), (0, 0, 1), 160, 120, 50.0)
+    inc = synth.incoherent_rays(20000, 3)
+    inc["t_min"][:100] = 3.0
+    inc["t_max"][:100] = 3.0          # degenerate
+    inc["t_max"][100:400] = 2.0
+    return grid, inc
+
+
+def _check(c, osc, name):
+    grid, inc = _rays()
+    for rays, kind in ((grid, "grid"), (inc, "incoherent")):
+        for mask in (0xFFFFFFFF, 0x2, 0x80000000):
+            want = osc.trace(rays, query_mask=mask)
+            for flags in (capi.FLAG_COHERENT, 0):          # linear lanes / Morton-sorted through a permutation
+                parity.assert_exact(c.cast(rays, query_mask=mask, flags=flags), want, f"{name} {kind} mask={mask:#x} flags={flags}")
+            b = c.cast(rays, query_mask=mask, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT)
+            assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
+    assert int((osc.trace(grid)["prim_id"] >= 0).sum()) > 50
+    cam = capi.camera_look((0, 0, -12), (0, 0, 1), 160, 120, 50.0)
+    parity.assert_exact(c.cast_grid(cam, 160, 120), osc.trace(grid), f"{name} cast_grid")
+
+
+def test_two_level_scene_gives_the_oracles_hits(built):
+    local, inst = _scene()
+    c = capi.Context(0)
+    c.upload_two_level_scene(local, inst)
+    assert c.is_available()
+    info = c.scene_info()
+    assert info["n_tris"] == 8 * 3000            # meshes are stored once, however often they are placed
+    _check(c, po.OracleTwoLevelScene(local, inst), "two-level")
+    c.close()
+
+
+def test_host_layout_rays_and_async_submit(built):
+    local, inst = _scene(4, 1500, 0.3, 5)
+    inst = inst[:4]
+    c = capi.Context(0)
+    c.upload_two_level_scene(local, inst)
+    osc = po.OracleTwoLevelScene(local, inst)
+    rays = synth.incoherent_rays(6000, 9)
+    want = osc.trace(rays)
+    host = po.make_host_rays(rays)
+    got = c.cast(host, flags=capi.FLAG_HOST_LAYOUT)
+    exp = po.unpack_hits(want, host)
+    assert got.tobytes() == exp.tobytes()
+    c.submit(rays)
+    assert c.has_pending()
+    parity.assert_exact(c.collect(), want, "async")
+    with pytest.raises(capi.MrtError) as e:          # hit tokens index a flat triangle array
+        c.cast(rays, flags=capi.FLAG_TOKEN_OUT)
+    assert e.value.status == capi.ERR_UNSUPPORTED
+    c.close()
+
+
+def test_instances_move_without_rebuilding_the_meshes(built):
+    """mrt_update_instances = set_instance_transform + refit_tlas: new transforms, the top level only."""
+    local, inst = _scene()
+    c = capi.Context(0)
+    c.upload_two_level_scene(local, inst)
+    rng = np.random.default_rng(5)
+    for step in range(3):
+        moved = inst.copy()
+        ang = rng.uniform(0, 2 * np.pi, inst.shape[0])
+        for i in range(inst.shape[0]):
+            ca, sa = np.cos(ang[i]), np.sin(ang[i])
+            rot = np.array([[ca, -sa, 0], [sa, ca, 0], [0, 0, 1]], dtype=np.float64) * (0.8 + 0.1 * step)   # uniform scale too
+            moved["basis"][i] = (rot @ inst["basis"][i].reshape(3, 3).astype(np.float64)).astype(np.float32).ravel()
+        moved["origin"] += rng.uniform(-0.5, 0.5, (inst.shape[0], 3)).astype(np.float32)
+        c.update_instances(moved)
+        _check(c, po.OracleTwoLevelScene(local, moved), f"moved {step}")
+    with pytest.raises(capi.MrtError):               # a refit moves instances; it does not swap their meshes
+        c.update_instances(inst[::-1].copy())
+    singular = inst.copy(); singular["basis"][2] = 0.0
+    with pytest.raises(capi.MrtError):
+        c.update_instances(singular)
+    _check(c, po.OracleTwoLevelScene(local, moved), "after refused updates")
+    c.close()
+
+
+def test_one_instance_and_scene_replacement(built):
+    """A TLAS with one leaf; a flat scene replaces a two-level one in the same context and vice versa."""
+    local, inst = synth.multi_mesh_instances(1, 800, 0.5, 3)
+    c = capi.Context(0)
+    c.upload_two_level_scene(local, inst)
+    _check(c, po.OracleTwoLevelScene(local, inst), "one instance")
+    world = synth.flatten_instances(local, inst)
+    capi.Scene(world).upload(c)
+    grid, inc = _rays()
+    parity.assert_exact(c.cast(inc), po.OracleScene(world).trace(inc), "flat after two-level")
+    with pytest.raises(capi.MrtError):
+        c.update_instances(inst)                     # no two-level scene resident any more
+    c.upload_two_level_scene(local, inst)
+    _check(c, po.OracleTwoLevelScene(local, inst), "two-level after flat")
+    bad = inst.copy(); bad["n_tris"][0] = local.shape[0] + 1
+    with pytest.raises(capi.MrtError):
+        c.upload_two_level_scene(local, bad)
+    c.close()
+
+
+def test_two_level_agrees_with_the_flattened_scene(built):
+    """The same placed meshes, flattened (mrt_flatten_instances semantics) and walked by the flat kernels:
+    prim ids agree except near-ties / edge grazes (each verified in fp64), t within 1e-5 (relative, or of the
+    scene scale) for all but 1e-4 of the hits and within 2e-4 for all -- the bounds tests/parity.py holds the oracle
+    to against the reference."""
+    local, inst = _scene(16, 4000, 0.2, 21)
+    world = synth.flatten_instances(local, inst)
+    ids = np.arange(world.shape[0], dtype=np.uint32)
+    layers = np.repeat(inst["layers"], inst["n_tris"]).astype(np.uint32)
+    c2, c1 = capi.Context(0), capi.Context(0)
+    c2.upload_two_level_scene(local, inst)
+    scene = capi.Scene(world, ids, layers)
+    scene.upload(c1)
+    w, h = 512, 512
+    cam = capi.camera_look((0, 0, -12), (0, 0, 1), w, h, 50.0)
+    a, b = c1.cast_grid(cam, w, h), c2.cast_grid(cam, w, h)
+    rays = po.grid_rays((0, 0, -12), (0, 0, 1), w, h, 50.0)
+    diff = np.nonzero(a["prim_id"] != b["prim_id"])[0]
+    assert diff.size <= max(2, (w * h) // 10000)
+    for i in diff:
+        assert parity.explain_mismatch(scene.tris, rays[i], int(b["prim_id"][i]), int(a["prim_id"][i])), f"ray {i}"
+    hit = (a["prim_id"] == b["prim_id"]) & (a["prim_id"] >= 0)
+    assert int(hit.sum()) > 10000
+    ta, tb = a["t"][hit].astype(np.float64), b["t"][hit].astype(np.float64)
+    err = np.abs(ta - tb)
+    assert (err > 1e-5 * np.maximum(ta, 1.0)).mean() <= parity.OUTLIER_FRACTION   # grazing hits are ill-conditioned in both walks
+    assert (err <= parity.T_REL_OUTLIER * np.maximum(ta, 1.0)).all()
+    assert np.abs(a["normal"][hit] - b["normal"][hit]).max() <= 2e-4
+    assert np.array_equal(a["hit_layers"][hit], b["hit_layers"][hit])
+    c1.close(); c2.close()
