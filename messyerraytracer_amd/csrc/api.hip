@@ -152,7 +152,8 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 // primary-ray grids), one lane per ray for everything else (sorted / incoherent batches).
 uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent)
 {
-	if (ctx->two_level) return mrt::MRT_KERNEL_TWO_LEVEL; // a two-level scene has one kernel
+	// a two-level scene has its own pair of kernels; the caller's "coherent" is taken at its word there
+	if (ctx->two_level) return coherent && ctx->opts.kernel != MRT_KERNEL_LANE ? mrt::MRT_KERNEL_TWO_LEVEL_PACKET : mrt::MRT_KERNEL_TWO_LEVEL;
 	// the 4-wide and the dual packet walks are retired (slower than the plain packet loop, and not
 	// exact for rays that lie in a box face): their ids run the packet kernel
 	if (ctx->opts.kernel == MRT_KERNEL_PACKET4 || ctx->opts.kernel == MRT_KERNEL_PACKET2) return MRT_KERNEL_PACKET;

@@ -532,6 +532,11 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 	const uint64_t blocks = (threads + MRT_WG - 1) / MRT_WG;
 	if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
 	dim3 grid((uint32_t)blocks), wg(MRT_WG);
+	if (p.kernel == MRT_KERNEL_TWO_LEVEL_PACKET) { // two-level scene, coherent batch: one wave per packet
+		if (any_hit) hipLaunchKernelGGL((trace_two_level_packet_kernel<true>), grid, wg, 0, stream, p);
+		else hipLaunchKernelGGL((trace_two_level_packet_kernel<false>), grid, wg, 0, stream, p);
+		return hipGetLastError();
+	}
 	if (p.kernel == MRT_KERNEL_TWO_LEVEL) { // two-level scene: one lane per ray, per-lane LDS stack
 		const size_t lds2 = (size_t)(MRT_WG / MRT_WAVE) * p.stack_depth * MRT_WAVE * sizeof(uint32_t);
 		if (any_hit) hipLaunchKernelGGL((trace_two_level_kernel<true>), grid, wg, lds2, stream, p);

@@ -148,3 +148,158 @@ __global__ __launch_bounds__(MRT_WG) void trace_two_level_kernel(const TracePara
 	}
 	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
 }
+
+// ---- the same walk for coherent batches: one wave = one packet of 64 rays --------------------------
+// The packet kernel of packet_kernel.h (generic octant form) extended over both levels: the node
+// index, the stack (one LDS dword per entry per wave) and the level are wave-uniform; nodes,
+// triangles and DevInstance rows are fetched once per wave through the scalar cache; a child or an
+// instance is entered when ANY lane's box test passed.  As there, a lane accepts hits only where its
+// own ray went: it carries an ownership bit per stack entry, and a lane whose world ray missed an
+// instance's box walks that instance's BLAS with an empty interval (no box test can pass), so every
+// lane reports exactly what the one-ray walk above reports.
+template <bool ANY_HIT>
+__global__ __launch_bounds__(MRT_WG) void trace_two_level_packet_kernel(const TraceParams p)
+{
+	__shared__ uint32_t wave_stack[MRT_WG / MRT_WAVE][MRT_PACKET_STACK];
+	if (skip_launch(p)) return;
+	uint64_t ray_idx = 0; uint32_t px = 0, py = 0;
+	if (!lane_ray_index(p, blockIdx.x, ray_idx, px, py)) return; // exited lanes drop out of every ballot
+	RayRegs r;
+	load_ray(p, ray_idx, px, py, r);
+	uint32_t *stack = wave_stack[threadIdx.x / MRT_WAVE];
+
+	float best_t = r.t_max, best_u = 0.0f, best_v = 0.0f;
+	uint32_t best_slot = 0xFFFFFFFFu, best_id = 0xFFFFFFFFu, best_inst = 0u;
+	const bool degenerate = r.t_min >= r.t_max;
+	float lim_t = degenerate ? -FLT_MAX : best_t; // empty interval: this lane takes no part
+	float ox = r.ox, oy = r.oy, oz = r.oz, dx = r.dx, dy = r.dy, dz = r.dz;
+	float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
+	float nrx = -(ox * ix), nry = -(oy * iy), nrz = -(oz * iz);
+	const float4 *nodes = reinterpret_cast<const float4 *>(p.nodes);
+	const float4 *hot = reinterpret_cast<const float4 *>(p.tri_hot);
+	const float4 *inst = reinterpret_cast<const float4 *>(p.instances);
+	uint32_t sp = 0, cur = 0, id_base = 0u, cur_inst = 0u; // wave-uniform
+	bool in_blas = false;                                  // wave-uniform
+	unsigned long long own_bits = 0ull;
+	bool own = true;
+
+	for (;;) {
+		cur = __builtin_amdgcn_readfirstlane(cur);
+		if (cur < kInstanceReturn) {
+			const float4 *n = nodes + (size_t)cur * 4u; // uniform address: scalar loads
+			const float4 a = n[0], b = n[1], c = n[2], d = n[3];
+			const float l0x = fma_(a.x, ix, nrx), l1x = fma_(b.x, ix, nrx);
+			const float l0y = fma_(a.y, iy, nry), l1y = fma_(b.y, iy, nry);
+			const float l0z = fma_(a.z, iz, nrz), l1z = fma_(b.z, iz, nrz);
+			const float r0x = fma_(c.x, ix, nrx), r1x = fma_(d.x, ix, nrx);
+			const float r0y = fma_(c.y, iy, nry), r1y = fma_(d.y, iy, nry);
+			const float r0z = fma_(c.z, iz, nrz), r1z = fma_(d.z, iz, nrz);
+			const float tl = fmaxf(fmaxf(fminf(l0x, l1x), fminf(l0y, l1y)), fmaxf(fminf(l0z, l1z), r.t_min));
+			const float tlx = fminf(fminf(fmaxf(l0x, l1x), fmaxf(l0y, l1y)), fminf(fmaxf(l0z, l1z), lim_t));
+			const float tr = fmaxf(fmaxf(fminf(r0x, r1x), fminf(r0y, r1y)), fmaxf(fminf(r0z, r1z), r.t_min));
+			const float trx = fminf(fminf(fmaxf(r0x, r1x), fmaxf(r0y, r1y)), fminf(fmaxf(r0z, r1z), lim_t));
+			const bool hl = tl <= tlx, hr = tr <= trx;
+			const unsigned long long ml = __ballot(hl), mr = __ballot(hr);
+			const uint32_t lref = __float_as_uint(a.w), rref = __float_as_uint(b.w);
+			if (ml != 0ull && mr != 0ull) {
+				const unsigned long long lfirst = __ballot(hl && (!hr || tl < tr));
+				const bool left_near = 2 * __builtin_popcountll(lfirst) >= __builtin_popcountll(ml | mr);
+				stack[sp] = left_near ? rref : lref;
+				own_bits = (left_near ? hr : hl) ? (own_bits | (1ull << sp)) : (own_bits & ~(1ull << sp));
+				sp++;
+				cur = left_near ? lref : rref; own = left_near ? hl : hr;
+				continue;
+			}
+			if (ml != 0ull) { cur = lref; own = hl; continue; }
+			if (mr != 0ull) { cur = rref; own = hr; continue; }
+		} else if (cur == kInstanceReturn) { // the BLAS is done: back to the world ray and the lane's own interval
+			ox = r.ox; oy = r.oy; oz = r.oz; dx = r.dx; dy = r.dy; dz = r.dz;
+			ix = safe_inv(dx); iy = safe_inv(dy); iz = safe_inv(dz);
+			nrx = -(ox * ix); nry = -(oy * iy); nrz = -(oz * iz);
+			lim_t = (degenerate || (ANY_HIT && best_slot != 0xFFFFFFFFu)) ? -FLT_MAX : best_t;
+			in_blas = false;
+		} else if (!in_blas) { // TLAS leaf: a run of instances, one at a time
+			const uint32_t slot0 = cur & 0x7FFFFFFFu;
+			const float4 *row = inst + (size_t)slot0 * 8u; // uniform address
+			const float4 m0 = row[0], m1 = row[1], m2 = row[2], meta = row[5];
+			const uint32_t flags = __float_as_uint(row[6].x);
+			if ((flags & 1u) == 0u) { // the rest of the leaf, owned by the same lanes
+				stack[sp] = kLeafBit | (slot0 + 1u);
+				own_bits = own ? (own_bits | (1ull << sp)) : (own_bits & ~(1ull << sp));
+				sp++;
+			}
+			if ((__float_as_uint(meta.w) & p.query_mask) != 0u) {
+				ox = fma_(m0.x, r.ox, fma_(m0.y, r.oy, fma_(m0.z, r.oz, m0.w)));
+				oy = fma_(m1.x, r.ox, fma_(m1.y, r.oy, fma_(m1.z, r.oz, m1.w)));
+				oz = fma_(m2.x, r.ox, fma_(m2.y, r.oy, fma_(m2.z, r.oz, m2.w)));
+				dx = fma_(m0.x, r.dx, fma_(m0.y, r.dy, m0.z * r.dz));
+				dy = fma_(m1.x, r.dx, fma_(m1.y, r.dy, m1.z * r.dz));
+				dz = fma_(m2.x, r.dx, fma_(m2.y, r.dy, m2.z * r.dz));
+				ix = safe_inv(dx); iy = safe_inv(dy); iz = safe_inv(dz);
+				nrx = -(ox * ix); nry = -(oy * iy); nrz = -(oz * iz);
+				if (!own) lim_t = -FLT_MAX; // this lane's world ray missed the instance's box
+				stack[sp] = kInstanceReturn; sp++;
+				in_blas = true; cur_inst = slot0;
+				id_base = __float_as_uint(meta.z);
+				cur = __float_as_uint(meta.y);
+				continue;
+			}
+		} else { // BLAS leaf: every lane whose own (mesh-space) ray hit the leaf's box tests its triangles
+			float lim_leaf = own ? lim_t : -FLT_MAX;
+			uint32_t slot = cur & 0x7FFFFFFFu;
+			bool last;
+			do {
+				const float4 *t3 = hot + (size_t)slot * 3u; // uniform address
+				const float4 q0 = t3[0], q1 = t3[1], q2 = t3[2];
+				last = (__float_as_uint(q2.w) & kLastInLeaf) != 0u;
+				const float pvx = fma_(dy, q2.z, -(dz * q2.y));
+				const float pvy = fma_(dz, q2.x, -(dx * q2.z));
+				const float pvz = fma_(dx, q2.y, -(dy * q2.x));
+				const float det = dot3(q1.x, q1.y, q1.z, pvx, pvy, pvz);
+				if (!(__builtin_fabsf(det) < 1e-8f)) {
+					const float inv_det = 1.0f / det;
+					const float tvx = ox - q0.x, tvy = oy - q0.y, tvz = oz - q0.z;
+					const float u = dot3(tvx, tvy, tvz, pvx, pvy, pvz) * inv_det;
+					if (!(u < 0.0f || u > 1.0f)) {
+						const float qvx = fma_(tvy, q1.z, -(tvz * q1.y));
+						const float qvy = fma_(tvz, q1.x, -(tvx * q1.z));
+						const float qvz = fma_(tvx, q1.y, -(tvy * q1.x));
+						const float v = dot3(dx, dy, dz, qvx, qvy, qvz) * inv_det;
+						if (!(v < 0.0f || u + v > 1.0f)) {
+							const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
+							const uint32_t id = id_base + __float_as_uint(q0.w);
+							if (!(t < r.t_min) && (t < lim_leaf || (t == lim_leaf && best_slot != 0xFFFFFFFFu && id < best_id))) {
+								best_t = t; best_u = u; best_v = v; best_slot = slot; best_id = id; best_inst = cur_inst;
+								lim_t = lim_leaf = ANY_HIT ? -FLT_MAX : t;
+							}
+						}
+					}
+				}
+				slot++;
+			} while (!last);
+			// any-hit: done when every lane is degenerate or has its answer (lanes outside this instance still wait)
+			if (ANY_HIT && __ballot(!degenerate && best_slot == 0xFFFFFFFFu) == 0ull) break;
+		}
+		if (sp == 0) break;
+		sp--; cur = stack[sp];
+		own = ((own_bits >> sp) & 1ull) != 0ull;
+	}
+
+	int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
+	if (best_slot != 0xFFFFFFFFu) {
+		prim = (int32_t)best_id;
+		if (p.out_fmt != OUT_BOOL8) {
+			const float4 *row = inst + (size_t)best_inst * 8u;
+			const float4 b0 = row[3], b1 = row[4], b2 = row[5];
+			const float4 no = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
+			nx = fma_(b0.x, no.x, fma_(b0.y, no.y, b0.z * no.z));
+			ny = fma_(b0.w, no.x, fma_(b1.x, no.y, b1.y * no.z));
+			nz = fma_(b1.z, no.x, fma_(b1.w, no.y, b2.x * no.z));
+			const float l2 = fma_(nx, nx, fma_(ny, ny, nz * nz));
+			if (l2 == 0.0f) { nx = ny = nz = 0.0f; }
+			else { const float l = __builtin_sqrtf(l2); nx /= l; ny /= l; nz /= l; }
+			layers = __float_as_uint(b2.w);
+		}
+	}
+	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
+}

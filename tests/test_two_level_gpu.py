@@ -43,9 +43,12 @@ def _check(c, osc, name):
     parity.assert_exact(c.cast_grid(cam, 160, 120), osc.trace(grid), f"{name} cast_grid")
 
 
-def test_two_level_scene_gives_the_oracles_hits(built):
+@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE])
+def test_two_level_scene_gives_the_oracles_hits(built, kernel):
+    """AUTO: the packet form for grids and batches flagged coherent, one lane per ray otherwise; KERNEL_LANE:
+    one lane per ray throughout."""
     local, inst = _scene()
-    c = capi.Context(0)
+    c = capi.Context(0, kernel=kernel)
     c.upload_two_level_scene(local, inst)
     assert c.is_available()
     info = c.scene_info()
