@@ -152,7 +152,7 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 // primary-ray grids), one lane per ray for everything else (sorted / incoherent batches).
 uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent)
 {
-	// a two-level scene has its own pair of kernels; the caller's "coherent" is taken at its word there
+	// a two-level scene has its own pair of kernels (two_level_kernel.h)
 	if (ctx->two_level) return coherent && ctx->opts.kernel != MRT_KERNEL_LANE ? mrt::MRT_KERNEL_TWO_LEVEL_PACKET : mrt::MRT_KERNEL_TWO_LEVEL;
 	// the 4-wide and the dual packet walks are retired (slower than the plain packet loop, and not
 	// exact for rays that lie in a box face): their ids run the packet kernel
@@ -273,8 +273,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	// Timed with the sort as pre-processing (last_sort_ms); last_trace_ms is the trace kernel alone.
 	const bool persistent_kind = p.kernel == MRT_KERNEL_LANE_PERSISTENT || p.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
 			p.kernel == MRT_KERNEL_LANE8_PERSISTENT;
-	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 4096 && ctx->opts.grid_tile != 1 && !persistent_kind &&
-			!ctx->two_level;
+	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 4096 && ctx->opts.grid_tile != 1 && !persistent_kind;
 	if (detect) {
 		uint32_t *d_auto = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);
 		HIP_TRY(ctx, mrt::launch_detect_grid(d_rays, p.in_fmt, count, p.tile_w_log2, ctx->d_counters + 16, d_auto, ctx->stream));
@@ -290,7 +289,10 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 		HIP_TRY(ctx, mrt::launch_trace(p, any, false, ctx->stream));
 		mrt::TraceParams lp = p;
 		lp.kernel = MRT_KERNEL_LANE; lp.lane_map = mrt::MAP_LINEAR; lp.auto_grid = nullptr; lp.skip_when = 0u;
-		if ((rc = launch_lane(ctx, lp, count, any, count >= 65536))) return rc;
+		if (ctx->two_level) { // the same pair for a two-level scene: packet form, else one lane per ray
+			lp.kernel = mrt::MRT_KERNEL_TWO_LEVEL;
+			HIP_TRY(ctx, mrt::launch_trace(lp, any, false, ctx->stream));
+		} else if ((rc = launch_lane(ctx, lp, count, any, count >= 65536))) return rc;
 	} else {
 		// large incoherent batches: resident waves that pull rays from a counter (no counting variant)
 		const bool persistent = !ctx->opts.count_visits && p.lane_map == mrt::MAP_LINEAR &&

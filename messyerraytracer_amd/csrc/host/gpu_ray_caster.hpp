@@ -67,6 +67,19 @@ public:
 				(uint32_t)triangles.size(), packed.data());
 		report(mrt_build_scene_device(ctx_, packed.data(), (uint32_t)packed.size(), 0), "build_scene_on_device");
 	}
+	// SceneTLAS on the device (scene_tlas.h:140-196): one BLAS per distinct mesh, a TLAS over the placed
+	// instances, nothing flattened; move_instances = set_instance_transform + refit_tlas.  Hit records carry
+	// the flat triangle ids of RayTracerServer::_rebuild_scene.
+	void upload_two_level_scene(const float *mesh_vertices9, uint32_t n_mesh_tris, const std::vector<mrt_instance> &instances)
+	{
+		if (!ctx_ || instances.empty()) return;
+		report(mrt_upload_two_level_scene(ctx_, mesh_vertices9, n_mesh_tris, instances.data(), (uint32_t)instances.size()), "upload_two_level_scene");
+	}
+	void move_instances(const std::vector<mrt_instance> &instances)
+	{
+		if (!ctx_ || instances.empty()) return;
+		report(mrt_update_instances(ctx_, instances.data(), (uint32_t)instances.size()), "move_instances");
+	}
 	// CWBVH is a Vulkan-path layout (cpp:351-411); accepted and ignored.
 	void upload_cwbvh(const void * /*cwbvh*/) {}
 

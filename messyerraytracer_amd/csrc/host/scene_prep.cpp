@@ -180,7 +180,7 @@ int prepare_scene(const mrt_tri64 *tris, uint32_t n_tris, const mrt_bvh_node32 *
 		out->bounds_hi[c] = dev[0].lmax[c] > dev[0].rmax[c] ? dev[0].lmax[c] : dev[0].rmax[c];
 	}
 
-	// ---- 4-wide collapse of the same tree for the packet kernel ----
+	// ---- 4-wide collapse of the same tree (MRT_KERNEL_LANE4_PERSISTENT) ----
 	// Children of a 4-node: start from the two children of a BVH2 node and keep opening the
 	// internal child with the largest half-area until there are four (or only leaves remain).
 	{

@@ -41,8 +41,8 @@ struct alignas(16) TriHot {
 static_assert(sizeof(TriHot) == 48, "TriHot must be 48 bytes");
 struct alignas(16) TriCold { float normal[3]; uint32_t pad; };
 
-// 4-wide node for the packet kernel: two levels of the BVH2 collapsed into one 128-byte
-// fetch (2 x s_load_dwordx16), halving the chain of dependent fetches a packet walks.
+// 4-wide node for the persistent lane kernel: two levels of the BVH2 collapsed into one 128-byte
+// line, halving the chain of dependent fetches a ray walks.
 // Built on the host from the same binned-SAH BVH2 (greedy: keep opening the child with
 // the largest surface area until there are 4).  Child refs use the DevNode encoding with
 // wide4 indices; an unused slot has ref == kSentinel.
@@ -88,7 +88,7 @@ enum LaneMap : uint32_t { MAP_LINEAR = 0, MAP_TILE8X8 = 1, MAP_AUTO = 2 };
 struct DevInstance;
 struct TraceParams {
 	const DevNode *nodes;
-	const Dev4Node *nodes4;    // packet kernel, 4-wide layout (may be null)
+	const Dev4Node *nodes4;    // 4-wide layout of the persistent lane kernel (may be null)
 	const Dev8Node *nodes8;    // 8-wide compressed layout (may be null)
 	const float *leaf_box;     // with nodes8: exact box {min xyz, -, max xyz, -} of the leaf that starts at a slot
 	const DevInstance *instances; // two-level scenes (kernel == MRT_KERNEL_TWO_LEVEL)
