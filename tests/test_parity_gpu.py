@@ -726,3 +726,45 @@ def test_rays_that_graze_box_faces(built, kernel, pitch):
         parity.assert_exact(c.cast(big, flags=flags), want, f"graze big kernel={kernel} flags={flags}")
     assert int((want["prim_id"] >= 0).sum()) > n and int((want["prim_id"] < 0).sum()) > 0
     c.close()
+
+
+@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM,
+                                    capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT, capi.KERNEL_LANE8_PERSISTENT])
+def test_non_finite_rays_do_not_disturb_their_neighbours(built, kernel):
+    """The reference only asserts ray validity in debug builds (RT_ASSERT_VALID_RAY); a release caller can hand
+    over NaN / infinite / zero-length rays.  They must terminate, must not change the answers of the valid rays
+    that share their wave or packet, and -- the comparisons being written the same way -- give what the oracle
+    gives for them."""
+    v = synth.soup(4000, 0.4, 13)
+    scene, osc = capi.Scene(v), po.OracleScene(v)
+    c = capi.Context(0, kernel=kernel)
+    scene.upload(c)
+    rays = np.tile(po.grid_rays((0, 0, -12), (0, 0, 1), 96, 96, 50.0), 8)[:70000].copy()   # large enough for the persistent kernels
+    rng = np.random.default_rng(3)
+    bad = rng.choice(rays.shape[0], 3000, replace=False)
+    vals = np.float32([np.nan, np.inf, -np.inf, 0.0, -0.0, 3.0e38, -3.0e38, 1e-30])
+    for k, i in enumerate(bad):
+        what = k % 6
+        if what == 0:
+            rays["direction"][i] = vals[rng.integers(0, 8, 3)]
+        elif what == 1:
+            rays["origin"][i] = vals[rng.integers(0, 8, 3)]
+        elif what == 2:
+            rays["direction"][i] = 0.0
+        elif what == 3:
+            rays["t_min"][i] = vals[rng.integers(0, 8)]
+        elif what == 4:
+            rays["t_max"][i] = vals[rng.integers(0, 8)]
+        else:
+            rays["origin"][i, rng.integers(0, 3)] = vals[rng.integers(0, 3)]
+            rays["direction"][i, rng.integers(0, 3)] = vals[rng.integers(0, 3)]
+    good = np.ones(rays.shape[0], dtype=bool)
+    good[bad] = False
+    want = osc.trace(rays)
+    for flags in (capi.FLAG_COHERENT, 0):
+        got = c.cast(rays, flags=flags)
+        parity.assert_exact(got[good], want[good], f"valid rays next to non-finite ones, kernel={kernel} flags={flags}")
+        assert np.array_equal(got["prim_id"][bad], want["prim_id"][bad]), f"non-finite rays, kernel={kernel} flags={flags}"
+        b = c.cast(rays, mode=capi.MODE_ANY_HIT, flags=flags | capi.FLAG_BOOL_OUT)
+        assert np.array_equal(b.astype(bool)[good], want["prim_id"][good] >= 0)
+    c.close()
