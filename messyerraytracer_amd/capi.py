@@ -19,7 +19,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SCENE, ERR_PENDING, ERR_NOT_PENDING,
 MODE_NEAREST, MODE_ANY_HIT = 0, 1
 FLAG_COHERENT, FLAG_RAYS_ON_DEVICE, FLAG_HITS_ON_DEVICE, FLAG_HOST_LAYOUT, FLAG_BOOL_OUT, FLAG_FORCE_SORT, FLAG_TOKEN_OUT, FLAG_ASYNC = (1 << i for i in range(8))
 TOKEN_MISS = 0xFFFFFFFF
-BUILD_TRIS_ON_DEVICE, BUILD_SAFE_HANDOFF = 1, 2
+BUILD_TRIS_ON_DEVICE, BUILD_SAFE_HANDOFF, BUILD_BLAS_ON_DEVICE = 1, 2, 4
 KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET, KERNEL_PACKET4, KERNEL_PACKET2, KERNEL_PACKET_ASM, KERNEL_LANE_PERSISTENT, \
     KERNEL_LANE4_PERSISTENT, KERNEL_LANE8_PERSISTENT = range(9)
 
@@ -91,7 +91,7 @@ def load():
     L.mrt_build_scene_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32]
     L.mrt_flatten_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32, C.c_void_p]
     L.mrt_build_instanced_scene_device.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
-    L.mrt_upload_two_level_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+    L.mrt_upload_two_level_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
     L.mrt_update_instances.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
     L.mrt_is_available.argtypes = [C.c_void_p]
     L.mrt_scene_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
@@ -264,12 +264,13 @@ class Context:
         self._chk(self.L.mrt_build_instanced_scene_device(self.h, _ptr(verts9), n_mesh_tris, _np(instances), instances.shape[0],
                                                           BUILD_TRIS_ON_DEVICE if on_device else 0))
 
-    def upload_two_level_scene(self, verts9, instances):
+    def upload_two_level_scene(self, verts9, instances, blas_on_device=False):
         """SceneTLAS::build_tlas: one BLAS per distinct mesh, a TLAS over the instances (nothing is flattened)."""
         verts9 = np.ascontiguousarray(verts9, dtype=np.float32)
         instances = np.ascontiguousarray(instances)
         assert instances.dtype == T.INSTANCE
-        self._chk(self.L.mrt_upload_two_level_scene(self.h, _np(verts9), verts9.size // 9, _np(instances), instances.shape[0]))
+        self._chk(self.L.mrt_upload_two_level_scene(self.h, _np(verts9), verts9.size // 9, _np(instances), instances.shape[0],
+                                                    BUILD_BLAS_ON_DEVICE if blas_on_device else 0))
 
     def update_instances(self, instances):
         """SceneTLAS::refit_tlas: the same instances with new transforms."""

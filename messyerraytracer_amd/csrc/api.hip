@@ -23,6 +23,7 @@ namespace mrt {
 hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream);
 hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t stream);
 hipError_t launch_expand_tokens(const TraceParams &p, const uint32_t *tokens, hipStream_t stream);
+hipError_t launch_offset_refs(DevNode *dst, const DevNode *src, uint32_t n, uint32_t node_base, uint32_t tri_base, void *stream);
 hipError_t launch_flatten_instances(const float *d_verts9, const mrt_instance *d_instances, const uint32_t *d_first_out,
 		uint32_t n_instances, uint32_t max_tris_per_instance, mrt_tri64 *d_out, void *stream);
 hipError_t launch_morton_keys(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t *keys, uint32_t *index, hipStream_t stream);
@@ -649,21 +650,61 @@ int mrt_build_instanced_scene_device(mrt_ctx *ctx, const float *verts9, uint32_t
 	return rc;
 }
 
+// Device-built BLASes for a two-level scene: every distinct mesh goes through device_build_lbvh on its own and
+// is moved to its place in the scene's arrays (node refs + node_base, leaf slots + tri_base).  h comes from
+// prepare_two_level(build_blas = false); on success the device arrays of ctx hold every BLAS and h knows
+// their boxes and depths.
+static int build_blases_on_device(mrt_ctx *ctx, mrt::TwoLevelHost *h, const float *verts9)
+{
+	uint32_t max_tris = 0;
+	for (uint32_t k = 0; k < h->n_blas; k++) if (h->blas[k].n_tris > max_tris) max_tris = h->blas[k].n_tris;
+	mrt_tri64 *staged = nullptr;
+	if (hipMalloc(&staged, (size_t)max_tris * sizeof(mrt_tri64)) != hipSuccess) return fail(ctx, MRT_ERR_OOM, "scene does not fit in device memory");
+	std::vector<mrt_tri64> tris(max_tris);
+	uint32_t tri_base = 0;
+	int rc = MRT_OK;
+	for (uint32_t k = 0; k < h->n_blas && rc == MRT_OK; k++) {
+		mrt::TwoLevelBlas &bl = h->blas[k];
+		rc = mrt_make_triangles(verts9 + (size_t)9 * bl.first_tri, nullptr, nullptr, bl.n_tris, tris.data()); // mesh-local ids, all layers
+		if (rc) { fail(ctx, rc, "two-level scene: bad mesh triangles"); break; }
+		hipError_t e = hipMemcpy(staged, tris.data(), (size_t)bl.n_tris * sizeof(mrt_tri64), hipMemcpyHostToDevice);
+		if (e != hipSuccess) { rc = fail(ctx, MRT_ERR_HIP, hipGetErrorString(e)); break; }
+		mrt::DeviceBuildResult b;
+		rc = mrt::device_build_lbvh(staged, bl.n_tris, false, false, false, (void *)ctx->stream, &b, ctx->err, sizeof(ctx->err));
+		if (rc) break;
+		e = mrt::launch_offset_refs(ctx->d_nodes + bl.root, b.nodes, b.n_nodes, bl.root, tri_base, (void *)ctx->stream);
+		if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_hot + tri_base, b.hot, (size_t)bl.n_tris * sizeof(mrt::TriHot), hipMemcpyDeviceToDevice, ctx->stream);
+		if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_cold + tri_base, b.cold, (size_t)bl.n_tris * sizeof(mrt::TriCold), hipMemcpyDeviceToDevice, ctx->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		(void)hipFree(b.nodes); (void)hipFree(b.hot); (void)hipFree(b.cold);
+		if (e != hipSuccess) { rc = fail(ctx, MRT_ERR_HIP, hipGetErrorString(e)); break; }
+		if (b.n_nodes != bl.n_tris - 1u) { rc = fail(ctx, MRT_ERR_BAD_BVH, "two-level scene: unexpected BLAS size"); break; }
+		bl.depth = b.depth;
+		for (int c = 0; c < 3; c++) { bl.lo[c] = b.bounds_lo[c]; bl.hi[c] = b.bounds_hi[c]; }
+		tri_base += bl.n_tris;
+	}
+	(void)hipFree(staged);
+	return rc;
+}
+
 // SceneTLAS::build_tlas + every MeshBLAS::build (scene_tlas.h:140-176, mesh_blas.h:86-138): nothing is flattened
 int mrt_upload_two_level_scene(mrt_ctx *ctx, const float *verts9, uint32_t n_mesh_tris, const mrt_instance *instances,
-		uint32_t n_instances)
+		uint32_t n_instances, uint32_t flags)
 {
 	if (!ctx) return MRT_ERR_INVALID;
 	if (!verts9 || !instances || n_instances == 0 || n_mesh_tris == 0) return fail(ctx, MRT_ERR_INVALID, "two-level scene: null or empty argument");
+	if (flags & ~(uint32_t)MRT_BUILD_BLAS_ON_DEVICE) return fail(ctx, MRT_ERR_INVALID, "two-level scene: unknown flag");
+	const bool on_device = (flags & MRT_BUILD_BLAS_ON_DEVICE) != 0;
 	int rc = drain_pending(ctx);
 	if (rc) return rc;
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	mrt::TwoLevelHost *h = new (std::nothrow) mrt::TwoLevelHost();
 	if (!h) return fail(ctx, MRT_ERR_OOM, "two-level scene: out of host memory");
+	auto drop = [&] { mrt::free_two_level(h); delete h; };
 	unsigned n_thr = std::thread::hardware_concurrency();
-	rc = mrt::prepare_two_level(verts9, n_mesh_tris, instances, n_instances, n_thr ? n_thr : 1u, h, ctx->err, sizeof(ctx->err));
+	rc = mrt::prepare_two_level(verts9, n_mesh_tris, instances, n_instances, n_thr ? n_thr : 1u, !on_device, h, ctx->err, sizeof(ctx->err));
 	if (rc) { delete h; return rc; }
-	if (h->depth > 64u) { mrt::free_two_level(h); delete h; return fail(ctx, MRT_ERR_UNSUPPORTED, "two-level scene: trees too deep for the per-lane stack"); }
+	if (!on_device && h->depth > 64u) { drop(); return fail(ctx, MRT_ERR_UNSUPPORTED, "two-level scene: trees too deep for the traversal stack"); }
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	free_scene(ctx);
 	hipError_t e;
@@ -671,14 +712,30 @@ int mrt_upload_two_level_scene(mrt_ctx *ctx, const float *verts9, uint32_t n_mes
 			(e = hipMalloc(&ctx->d_hot, (size_t)h->n_tris * sizeof(mrt::TriHot) + 16)) != hipSuccess ||
 			(e = hipMalloc(&ctx->d_cold, (size_t)h->n_tris * sizeof(mrt::TriCold))) != hipSuccess ||
 			(e = hipMalloc(&ctx->d_instances, (size_t)h->n_inst * sizeof(mrt::DevInstance))) != hipSuccess) {
-		mrt::free_two_level(h); delete h; free_scene(ctx);
+		drop(); free_scene(ctx);
 		return fail(ctx, MRT_ERR_OOM, "scene does not fit in device memory");
 	}
-	e = hipMemcpy(ctx->d_nodes, h->nodes, (size_t)h->n_nodes * sizeof(mrt::DevNode), hipMemcpyHostToDevice);
-	if (e == hipSuccess) e = hipMemcpy(ctx->d_hot, h->hot, (size_t)h->n_tris * sizeof(mrt::TriHot), hipMemcpyHostToDevice);
-	if (e == hipSuccess) e = hipMemcpy(ctx->d_cold, h->cold, (size_t)h->n_tris * sizeof(mrt::TriCold), hipMemcpyHostToDevice);
+	if (on_device) {
+		hipEvent_t e0, e1;
+		HIP_TRY(ctx, hipEventCreate(&e0)); HIP_TRY(ctx, hipEventCreate(&e1));
+		(void)hipEventRecord(e0, ctx->stream);
+		rc = build_blases_on_device(ctx, h, verts9);
+		if (!rc) rc = mrt::refit_two_level(h, instances, n_instances, ctx->err, sizeof(ctx->err));
+		if (!rc && h->depth > 64u) rc = fail(ctx, MRT_ERR_UNSUPPORTED, "two-level scene: device-built trees too deep for the traversal stack: build on the host");
+		if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); drop(); free_scene(ctx); return rc; }
+		e = hipMemcpy(ctx->d_nodes, h->nodes, (size_t)h->n_tlas_nodes * sizeof(mrt::DevNode), hipMemcpyHostToDevice);
+		(void)hipEventRecord(e1, ctx->stream);
+		(void)hipEventSynchronize(e1);
+		float ms = 0.0f;
+		if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ctx->stats.last_build_ms = ms;
+		(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+	} else {
+		e = hipMemcpy(ctx->d_nodes, h->nodes, (size_t)h->n_nodes * sizeof(mrt::DevNode), hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = hipMemcpy(ctx->d_hot, h->hot, (size_t)h->n_tris * sizeof(mrt::TriHot), hipMemcpyHostToDevice);
+		if (e == hipSuccess) e = hipMemcpy(ctx->d_cold, h->cold, (size_t)h->n_tris * sizeof(mrt::TriCold), hipMemcpyHostToDevice);
+	}
 	if (e == hipSuccess) e = hipMemcpy(ctx->d_instances, h->inst, (size_t)h->n_inst * sizeof(mrt::DevInstance), hipMemcpyHostToDevice);
-	if (e != hipSuccess) { mrt::free_two_level(h); delete h; free_scene(ctx); return fail(ctx, MRT_ERR_HIP, hipGetErrorString(e)); }
+	if (e != hipSuccess) { drop(); free_scene(ctx); return fail(ctx, MRT_ERR_HIP, hipGetErrorString(e)); }
 	std::free(h->hot); std::free(h->cold); h->hot = nullptr; h->cold = nullptr; // the device has them; a refit only needs nodes + instances
 	ctx->two_level = h;
 	ctx->n_nodes = h->n_nodes; ctx->n_tris = h->n_tris; ctx->depth = h->depth;

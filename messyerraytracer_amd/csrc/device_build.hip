@@ -417,8 +417,25 @@ __global__ __launch_bounds__(LBVH_WG) void flatten_instances_kernel(const float 
 	dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d;
 }
 
+// A BLAS built on its own (refs from 0) into its place in a two-level scene's node array
+__global__ __launch_bounds__(LBVH_WG) void offset_refs_kernel(DevNode *dst, const DevNode *src, uint32_t n, uint32_t node_base, uint32_t tri_base)
+{
+	const uint32_t i = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (i >= n) return;
+	DevNode g = src[i];
+	auto fix = [&](uint32_t ref) { return ref < kSentinel ? ref + node_base : (ref >= kLeafBit ? (kLeafBit | ((ref & 0x7FFFFFFFu) + tri_base)) : ref); };
+	g.left_ref = fix(g.left_ref); g.right_ref = fix(g.right_ref);
+	dst[i] = g;
+}
+
 } // namespace
 
+hipError_t launch_offset_refs(DevNode *dst, const DevNode *src, uint32_t n, uint32_t node_base, uint32_t tri_base, void *stream)
+{
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(offset_refs_kernel, dim3((n + LBVH_WG - 1) / LBVH_WG), dim3(LBVH_WG), 0, (hipStream_t)stream, dst, src, n, node_base, tri_base);
+	return hipGetLastError();
+}
 hipError_t launch_flatten_instances(const float *d_verts9, const mrt_instance *d_instances, const uint32_t *d_first_out,
 		uint32_t n_instances, uint32_t max_tris_per_instance, mrt_tri64 *d_out, void *stream)
 {

@@ -73,7 +73,7 @@ public:
 	void upload_two_level_scene(const float *mesh_vertices9, uint32_t n_mesh_tris, const std::vector<mrt_instance> &instances)
 	{
 		if (!ctx_ || instances.empty()) return;
-		report(mrt_upload_two_level_scene(ctx_, mesh_vertices9, n_mesh_tris, instances.data(), (uint32_t)instances.size()), "upload_two_level_scene");
+		report(mrt_upload_two_level_scene(ctx_, mesh_vertices9, n_mesh_tris, instances.data(), (uint32_t)instances.size(), 0), "upload_two_level_scene");
 	}
 	void move_instances(const std::vector<mrt_instance> &instances)
 	{

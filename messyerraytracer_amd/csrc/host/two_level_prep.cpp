@@ -142,7 +142,7 @@ int refit_two_level(TwoLevelHost *h, const mrt_instance *instances, uint32_t n, 
 }
 
 int prepare_two_level(const float *verts9, uint32_t n_mesh_tris, const mrt_instance *instances, uint32_t n,
-		uint32_t n_threads, TwoLevelHost *out, char *err, size_t err_len)
+		uint32_t n_threads, bool build_blas, TwoLevelHost *out, char *err, size_t err_len)
 {
 	if (!verts9 || !instances || !out || n == 0 || n_mesh_tris == 0) return fail_(err, err_len, MRT_ERR_INVALID, "two-level scene: null or empty argument");
 	*out = TwoLevelHost();
@@ -168,6 +168,28 @@ int prepare_two_level(const float *verts9, uint32_t n_mesh_tris, const mrt_insta
 	}
 	if (flat >= 0x7FFFFFFFull || unique_tris >= 0x7FFFFFFFull) return fail_(err, err_len, MRT_ERR_UNSUPPORTED, "two-level scene: more than 2^31-1 triangles");
 	const uint32_t tlas_cap = 2u * n; // a BVH2 over n leaves has fewer than n inner nodes; the wrapped root leaf needs 1
+	if (!build_blas) {
+		// the caller builds every BLAS on the device (an LBVH over k >= 2 triangles has k - 1 nodes, one
+		// triangle per leaf) at the roots laid out here, fills in blas[].lo/hi/depth and calls refit_two_level
+		TwoLevelHost h;
+		uint64_t n_nodes = tlas_cap;
+		for (auto &b : blas) {
+			if (b.n_tris < 2) return fail_(err, err_len, MRT_ERR_UNSUPPORTED, "two-level scene: a mesh of one triangle needs the host builder");
+			b.root = (uint32_t)n_nodes; n_nodes += b.n_tris - 1u;
+		}
+		if (n_nodes >= kInstanceReturn) return fail_(err, err_len, MRT_ERR_UNSUPPORTED, "two-level scene: too many nodes");
+		h.nodes = (DevNode *)std::calloc((size_t)tlas_cap, sizeof(DevNode));
+		h.inst = (DevInstance *)std::calloc(n, sizeof(DevInstance));
+		h.blas = (TwoLevelBlas *)std::malloc(blas.size() * sizeof(TwoLevelBlas));
+		h.inst_blas = (uint32_t *)std::malloc((size_t)n * sizeof(uint32_t));
+		if (!h.nodes || !h.inst || !h.blas || !h.inst_blas) { free_two_level(&h); return fail_(err, err_len, MRT_ERR_OOM, "two-level scene: out of host memory"); }
+		h.n_nodes = (uint32_t)n_nodes; h.tlas_cap = tlas_cap; h.n_tris = (uint32_t)unique_tris; h.n_inst = n; h.n_blas = (uint32_t)blas.size();
+		h.flat_tris = flat;
+		std::memcpy(h.blas, blas.data(), blas.size() * sizeof(TwoLevelBlas));
+		std::memcpy(h.inst_blas, inst_blas.data(), (size_t)n * sizeof(uint32_t));
+		*out = h;
+		return MRT_OK;
+	}
 	// every BLAS: triangles with mesh-local ids and all layers (the mask lives in the instance), SAH BVH2, device layout
 	std::vector<DeviceSceneHost> built(blas.size());
 	auto cleanup = [&] { for (auto &s : built) free_scene_host(s); };

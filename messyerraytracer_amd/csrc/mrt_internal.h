@@ -176,8 +176,10 @@ struct TwoLevelHost {
 };
 void free_two_level(TwoLevelHost *h);
 // Builds every BLAS (binned SAH, as MeshBLAS::build) and the TLAS over the instances' world boxes.
+// build_blas = false: only groups the instances by mesh and lays the BLAS roots out (device-built BLASes).
 int prepare_two_level(const float *verts9, uint32_t n_mesh_tris, const mrt_instance *instances, uint32_t n_instances,
-		uint32_t n_threads, TwoLevelHost *out, char *err, size_t err_len);
+		uint32_t n_threads, bool build_blas, TwoLevelHost *out, char *err, size_t err_len);
+
 // New transforms for the same instances: inverse, world box, TLAS rebuilt into nodes[0, tlas_cap) and inst[].
 int refit_two_level(TwoLevelHost *h, const mrt_instance *instances, uint32_t n_instances, char *err, size_t err_len);
 

@@ -47,7 +47,7 @@ def test_null_arguments_are_rejected_not_crashed(built):
     assert L.mrt_flatten_instances(None, None, 0, None, 0, 0, None) == capi.ERR_INVALID
     assert L.mrt_build_instanced_scene_device(None, None, 0, None, 0, 0) == capi.ERR_INVALID
     assert L.mrt_expand_tokens(None, None, None, None, 0, 0, None) == capi.ERR_INVALID
-    assert L.mrt_upload_two_level_scene(None, None, 0, None, 0) == capi.ERR_INVALID
+    assert L.mrt_upload_two_level_scene(None, None, 0, None, 0, 0) == capi.ERR_INVALID
     assert L.mrt_update_instances(None, None, 0) == capi.ERR_INVALID
     assert L.mrt_expand_grid_tokens(None, None, 0, 0, 0, 0, None, None, None) == capi.ERR_INVALID
     assert C.sizeof(capi.Stats) == 80 and T.INSTANCE.itemsize == 64

@@ -153,3 +153,29 @@ def test_two_level_agrees_with_the_flattened_scene(built):
     assert np.abs(a["normal"][hit] - b["normal"][hit]).max() <= 2e-4
     assert np.array_equal(a["hit_layers"][hit], b["hit_layers"][hit])
     c1.close(); c2.close()
+
+
+def test_blases_built_on_the_device(built):
+    """MRT_BUILD_BLAS_ON_DEVICE: every mesh's BVH from the device builder (LBVH) instead of the host SAH builder.
+    Different trees, the same hit records: a result does not depend on which valid BVH is walked."""
+    local, inst = _scene()
+    osc = po.OracleTwoLevelScene(local, inst)
+    c = capi.Context(0)
+    c.upload_two_level_scene(local, inst, blas_on_device=True)
+    assert c.stats()["last_build_ms"] > 0.0
+    assert c.scene_info()["n_tris"] == 8 * 3000
+    _check(c, osc, "device-built BLASes")
+    moved = inst.copy()
+    moved["origin"] += np.float32([0.25, 0.5, -0.125])
+    c.update_instances(moved)
+    _check(c, po.OracleTwoLevelScene(local, moved), "device-built BLASes, moved")
+    # against the host-built form of the same scene, whole grid, byte for byte
+    h = capi.Context(0)
+    h.upload_two_level_scene(local, moved)
+    cam = capi.camera_look((0, 0, -12), (0, 0, 1), 512, 512, 50.0)
+    assert c.cast_grid(cam, 512, 512).tobytes() == h.cast_grid(cam, 512, 512).tobytes()
+    one_local, one = synth.multi_mesh_instances(1, 1, 0.5, 3)     # a one-triangle mesh has no device-built tree
+    with pytest.raises(capi.MrtError) as e:
+        c.upload_two_level_scene(one_local, one, blas_on_device=True)
+    assert e.value.status == capi.ERR_UNSUPPORTED
+    c.close(); h.close()
