@@ -179,3 +179,38 @@ def test_blases_built_on_the_device(built):
         c.upload_two_level_scene(one_local, one, blas_on_device=True)
     assert e.value.status == capi.ERR_UNSUPPORTED
     c.close(); h.close()
+
+
+def test_c5_full_grid_two_level_against_flattened(built):
+    """Config C5 at full size (64 meshes x 156 250 triangles, 8192^2 primary rays), both scenes built on the
+    device: the two-level walk and the flat walk over the flattened instances.  The triangles are a few
+    pixels wide here and the mesh-space ray carries an origin rounding of ulp(12) = 1e-6, i.e. 1e-4 of a triangle:
+    that share of the rays (those within it of an edge) may land on the neighbouring triangle or past a silhouette.
+    Bounds: hit / miss flips <= 5e-4 of the rays, prim differences <= 2e-3; on the common hits t within 1e-5 of
+    max(t, 1) for all but 1e-4 of them and within 2e-4 for all."""
+    cfg = synth.CONFIGS["C5"]
+    local, inst = synth.multi_mesh_instances(cfg["n_meshes"], cfg["tris_per_mesh"], cfg["s"], cfg["seed"])
+    w, h = cfg["grid"]
+    cam = capi.camera_look(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
+    c = capi.Context(0)
+    c.build_instanced_scene_device(local, inst)
+    flat = c.cast_grid(cam, w, h)
+    fp, ft = flat["prim_id"].copy(), flat["t"].copy()
+    del flat
+    c.upload_two_level_scene(local, inst, blas_on_device=True)
+    two = c.cast_grid(cam, w, h)
+    tp, tt = two["prim_id"].copy(), two["t"].copy()
+    del two
+    c.close()
+    n = w * h
+    assert int((fp >= 0).sum()) > n // 2
+    flips, diffs = int(((fp >= 0) != (tp >= 0)).sum()), int((fp != tp).sum())
+    hit = (fp == tp) & (fp >= 0)
+    a, b = ft[hit].astype(np.float64), tt[hit].astype(np.float64)
+    err = np.abs(a - b)
+    scale = np.maximum(a, 1.0)
+    loose = int((err > 1e-5 * scale).sum())
+    print(f"C5 two-level vs flat: {flips} hit/miss flips, {diffs} prim differences of {n}; {loose} of {int(hit.sum())} common hits beyond 1e-5, max {float((err / scale).max()):.3g}")
+    assert flips <= n // 2000 and diffs <= n // 500
+    assert loose <= hit.sum() // 10000
+    assert (err <= 2e-4 * scale).all()
