@@ -204,7 +204,7 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 			(ctx->opts.kernel == MRT_KERNEL_AUTO && persistent));
 	if ((wide4 || wide8) && !ctx->opts.count_visits) persistent = true;
 	if (!persistent || ctx->opts.count_visits) {
-		p.kernel = MRT_KERNEL_LANE;
+		p.kernel = ctx->two_level ? mrt::MRT_KERNEL_TWO_LEVEL : MRT_KERNEL_LANE;
 		HIP_TRY(ctx, mrt::launch_trace(p, any_hit, ctx->opts.count_visits != 0, ctx->stream));
 		return MRT_OK;
 	}
@@ -221,6 +221,7 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 		ovf = (uint32_t *)ctx->overflow.ptr;
 	}
 	p.kernel = wide8 ? MRT_KERNEL_LANE8_PERSISTENT : (wide4 ? MRT_KERNEL_LANE4_PERSISTENT : MRT_KERNEL_LANE_PERSISTENT);
+	if (ctx->two_level) p.kernel = mrt::MRT_KERNEL_TWO_LEVEL_PERSISTENT; // the 2-wide walk over both levels (need = ctx->depth)
 	// eight ray counters (one per region of the batch), 128 bytes apart
 	unsigned long long *next_ray = ctx->d_counters + 16 + 1026;
 	HIP_TRY(ctx, hipMemsetAsync(next_ray, 0, 128 * sizeof(unsigned long long), ctx->stream));
@@ -290,15 +291,13 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 		HIP_TRY(ctx, mrt::launch_trace(p, any, false, ctx->stream));
 		mrt::TraceParams lp = p;
 		lp.kernel = MRT_KERNEL_LANE; lp.lane_map = mrt::MAP_LINEAR; lp.auto_grid = nullptr; lp.skip_when = 0u;
-		if (ctx->two_level) { // the same pair for a two-level scene: packet form, else one lane per ray
-			lp.kernel = mrt::MRT_KERNEL_TWO_LEVEL;
-			HIP_TRY(ctx, mrt::launch_trace(lp, any, false, ctx->stream));
-		} else if ((rc = launch_lane(ctx, lp, count, any, count >= 65536))) return rc;
+		if ((rc = launch_lane(ctx, lp, count, any, count >= 65536))) return rc; // (a two-level scene: its own lane kernels)
 	} else {
 		// large incoherent batches: resident waves that pull rays from a counter (no counting variant)
 		const bool persistent = !ctx->opts.count_visits && p.lane_map == mrt::MAP_LINEAR &&
-				(persistent_kind || (ctx->opts.kernel == MRT_KERNEL_AUTO && p.kernel == MRT_KERNEL_LANE && count >= 65536));
-		if (persistent_kind || p.kernel == MRT_KERNEL_LANE) {
+				(persistent_kind || (ctx->opts.kernel == MRT_KERNEL_AUTO && count >= 65536 &&
+					(p.kernel == MRT_KERNEL_LANE || p.kernel == mrt::MRT_KERNEL_TWO_LEVEL)));
+		if (persistent_kind || p.kernel == MRT_KERNEL_LANE || p.kernel == mrt::MRT_KERNEL_TWO_LEVEL) {
 			if ((rc = launch_lane(ctx, p, count, any, persistent))) return rc;
 		} else HIP_TRY(ctx, mrt::launch_trace(p, any, ctx->opts.count_visits != 0, ctx->stream));
 	}

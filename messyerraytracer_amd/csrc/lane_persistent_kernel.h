@@ -54,9 +54,14 @@ struct PersistParams {
 // byte k of a packed word as a float (v_cvt_f32_ubyteK)
 __device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }
 
-template <bool ANY_HIT, int WIDTH> // WIDTH: children per node step = 2 (DevNode), 4 (Dev4Node) or 8 (Dev8Node)
+// TL: a two-level scene (two_level_kernel.h; WIDTH 2 only): p.nodes holds the TLAS and every BLAS, a TLAS leaf
+// is a run of DevInstance rows, a lane inside an instance walks with its mesh-space ray and the marker
+// kInstanceReturn on its stack takes it back to the world ray.
+template <bool ANY_HIT, int WIDTH, bool TL = false> // WIDTH: children per node step = 2 (DevNode), 4 (Dev4Node) or 8 (Dev8Node)
 __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent_kernel(const TraceParams p, const PersistParams q)
 {
+	static_assert(!TL || WIDTH == 2, "two-level scenes are walked 2-wide");
+	constexpr uint32_t kNode = TL ? kInstanceReturn : kSentinel; // refs below this are inner nodes
 	extern __shared__ uint32_t lds_stack[];
 	if (skip_launch(p)) return;
 	const uint32_t lane = threadIdx.x & (MRT_WAVE - 1), wave = threadIdx.x / MRT_WAVE;
@@ -74,6 +79,11 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 	float ix = 0, iy = 0, iz = 0, nrx = 0, nry = 0, nrz = 0;
 	float best_t = 0, best_u = 0, best_v = 0;
 	uint32_t best_slot = 0xFFFFFFFFu, best_id = 0xFFFFFFFFu;
+	// TL: the ray being walked (the world ray, or its image in the mesh space of the instance the lane is in)
+	float cox = 0, coy = 0, coz = 0, cdx = 0, cdy = 0, cdz = 0;
+	uint32_t id_base = 0u, cur_inst = 0u, best_inst = 0u;
+	bool in_blas = false;
+	const float4 *inst = reinterpret_cast<const float4 *>(p.instances);
 	uint32_t cur = kSentinel; // kSentinel = this lane has no work
 	uint32_t depth = 0;
 	bool has_ray = false;
@@ -102,7 +112,19 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 			// (not finish_ray(): its output-format branch around these loads measured 11 % slower here,
 			// 8.6 against 7.7 ms at C4; the lookups are unconditional in this kernel)
 			int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
-			if (best_slot != 0xFFFFFFFFu) {
+			if (TL && best_slot != 0xFFFFFFFFu) { // flat id, the instance's mask, normalize(basis * mesh-space normal)
+				prim = (int32_t)best_id;
+				const float4 *row = inst + (size_t)best_inst * 8u;
+				const float4 b0 = row[3], b1 = row[4], b2 = row[5];
+				const float4 no = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
+				nx = fma_(b0.x, no.x, fma_(b0.y, no.y, b0.z * no.z));
+				ny = fma_(b0.w, no.x, fma_(b1.x, no.y, b1.y * no.z));
+				nz = fma_(b1.z, no.x, fma_(b1.w, no.y, b2.x * no.z));
+				const float l2 = fma_(nx, nx, fma_(ny, ny, nz * nz));
+				if (l2 == 0.0f) { nx = ny = nz = 0.0f; }
+				else { const float l = __builtin_sqrtf(l2); nx /= l; ny /= l; nz /= l; }
+				layers = __float_as_uint(b2.w);
+			} else if (best_slot != 0xFFFFFFFFu) {
 				prim = (int32_t)p.tri_hot[best_slot].id;
 				layers = p.tri_hot[best_slot].layers;
 				const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
@@ -159,6 +181,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 					else {
 						ix = safe_inv(r.dx); iy = safe_inv(r.dy); iz = safe_inv(r.dz);
 						nrx = -(r.ox * ix); nry = -(r.oy * iy); nrz = -(r.oz * iz);
+						if (TL) { cox = r.ox; coy = r.oy; coz = r.oz; cdx = r.dx; cdy = r.dy; cdz = r.dz; in_blas = false; }
 						cur = 0;
 					}
 				}
@@ -170,6 +193,13 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 		for (;;) {
 			// NODE phase (wave-uniform loop, lanes at an inner node take the step)
 			while (__ballot(cur < kSentinel) != 0ull) {
+				if (TL && cur == kInstanceReturn) { // the BLAS is done: back to the world ray
+					cox = r.ox; coy = r.oy; coz = r.oz; cdx = r.dx; cdy = r.dy; cdz = r.dz;
+					ix = safe_inv(cdx); iy = safe_inv(cdy); iz = safe_inv(cdz);
+					nrx = -(cox * ix); nry = -(coy * iy); nrz = -(coz * iz);
+					in_blas = false;
+					cur = pop();
+				}
 				if (WIDTH == 8 && cur < kSentinel) { // 8-wide compressed node: one 128-byte line, 96 bytes read
 					const float4 *n = nodes8 + (size_t)cur * 8u;
 					const float4 h = n[0], qa = n[1], qb = n[2], qc = n[3], ra = n[4], rb = n[5];
@@ -262,7 +292,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 						cur = pick(key[0]);
 					}
 				}
-				if (WIDTH == 2 && cur < kSentinel) { // dual-AABB node: glsl:243-318
+				if (WIDTH == 2 && cur < kNode) { // dual-AABB node: glsl:243-318
 					const float4 *n = nodes + (size_t)cur * 4u;
 					const float4 a = n[0], b = n[1], c = n[2], d = n[3];
 					const float l0x = fma_(a.x, ix, nrx), l1x = fma_(b.x, ix, nrx);
@@ -288,7 +318,30 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 				if ((uint32_t)__builtin_popcountll(__ballot(cur >= kLeafBit)) >= q.leaf_wait) break;
 			}
 			// LEAF phase: every lane at a leaf intersects that leaf (glsl:166-192), then pops
-			if (cur >= kLeafBit) {
+			if (TL && cur >= kLeafBit && !in_blas) {
+				// TLAS leaf: a run of instances, one at a time (tiny_bvh.h:3320-3360); the rest of the run goes back on the stack
+				const uint32_t slot0 = cur & 0x7FFFFFFFu;
+				const float4 *row = inst + (size_t)slot0 * 8u;
+				const float4 m0 = row[0], m1 = row[1], m2 = row[2], meta = row[5];
+				if ((__float_as_uint(row[6].x) & 1u) == 0u) push(kLeafBit | (slot0 + 1u));
+				if ((__float_as_uint(meta.w) & p.query_mask) != 0u) {
+					cox = fma_(m0.x, r.ox, fma_(m0.y, r.oy, fma_(m0.z, r.oz, m0.w)));
+					coy = fma_(m1.x, r.ox, fma_(m1.y, r.oy, fma_(m1.z, r.oz, m1.w)));
+					coz = fma_(m2.x, r.ox, fma_(m2.y, r.oy, fma_(m2.z, r.oz, m2.w)));
+					cdx = fma_(m0.x, r.dx, fma_(m0.y, r.dy, m0.z * r.dz));
+					cdy = fma_(m1.x, r.dx, fma_(m1.y, r.dy, m1.z * r.dz));
+					cdz = fma_(m2.x, r.dx, fma_(m2.y, r.dy, m2.z * r.dz));
+					ix = safe_inv(cdx); iy = safe_inv(cdy); iz = safe_inv(cdz);
+					nrx = -(cox * ix); nry = -(coy * iy); nrz = -(coz * iz);
+					push(kInstanceReturn);
+					in_blas = true; cur_inst = slot0;
+					id_base = __float_as_uint(meta.z);
+					cur = __float_as_uint(meta.y);
+				} else cur = pop();
+			} else if (cur >= kLeafBit) {
+				// the ray the triangles are tested with: the world ray, or (TL) the mesh-space ray of the instance
+				const float tox = TL ? cox : r.ox, toy = TL ? coy : r.oy, toz = TL ? coz : r.oz;
+				const float tdx = TL ? cdx : r.dx, tdy = TL ? cdy : r.dy, tdz = TL ? cdz : r.dz;
 				uint32_t slot = cur & 0x7FFFFFFFu;
 				const uint32_t leaf_first = slot;
 				bool last;
@@ -296,23 +349,23 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 					const float4 *t3 = hot + (size_t)slot * 3u;
 					const float4 q0 = t3[0], q1 = t3[1], q2 = t3[2];
 					last = (__float_as_uint(q2.w) & kLastInLeaf) != 0u;
-					if ((__float_as_uint(q1.w) & p.query_mask) != 0u) {
-						const float pvx = fma_(r.dy, q2.z, -(r.dz * q2.y));
-						const float pvy = fma_(r.dz, q2.x, -(r.dx * q2.z));
-						const float pvz = fma_(r.dx, q2.y, -(r.dy * q2.x));
+					if (TL || (__float_as_uint(q1.w) & p.query_mask) != 0u) { // TL: the mask was applied to the instance
+						const float pvx = fma_(tdy, q2.z, -(tdz * q2.y));
+						const float pvy = fma_(tdz, q2.x, -(tdx * q2.z));
+						const float pvz = fma_(tdx, q2.y, -(tdy * q2.x));
 						const float det = dot3(q1.x, q1.y, q1.z, pvx, pvy, pvz);
 						if (!(__builtin_fabsf(det) < 1e-8f)) {
 							const float inv_det = 1.0f / det;
-							const float tvx = r.ox - q0.x, tvy = r.oy - q0.y, tvz = r.oz - q0.z;
+							const float tvx = tox - q0.x, tvy = toy - q0.y, tvz = toz - q0.z;
 							const float u = dot3(tvx, tvy, tvz, pvx, pvy, pvz) * inv_det;
 							if (!(u < 0.0f || u > 1.0f)) {
 								const float qvx = fma_(tvy, q1.z, -(tvz * q1.y));
 								const float qvy = fma_(tvz, q1.x, -(tvx * q1.z));
 								const float qvz = fma_(tvx, q1.y, -(tvy * q1.x));
-								const float v = dot3(r.dx, r.dy, r.dz, qvx, qvy, qvz) * inv_det;
+								const float v = dot3(tdx, tdy, tdz, qvx, qvy, qvz) * inv_det;
 								if (!(v < 0.0f || u + v > 1.0f)) {
 									const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
-									const uint32_t id = __float_as_uint(q0.w);
+									const uint32_t id = (TL ? id_base : 0u) + __float_as_uint(q0.w); // TL: flat id
 									if (!(t < r.t_min) && (t < best_t || (t == best_t && best_slot != 0xFFFFFFFFu && id < best_id))) {
 										// 8-wide: the quantised boxes that led here are looser than the exact ones; accept
 										// the hit only if the ray passes the slab test on the leaf's exact box, as it does
@@ -333,6 +386,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 										}
 										if (entered) {
 											best_t = t; best_u = u; best_v = v; best_slot = slot; best_id = id;
+											if (TL) best_inst = cur_inst;
 											if (ANY_HIT) last = true;
 										}
 									}

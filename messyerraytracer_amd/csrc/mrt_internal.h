@@ -152,6 +152,7 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 constexpr uint32_t kInstanceReturn = 0x7FFFFFFEu; // stack marker: back from a BLAS to the TLAS walk
 constexpr uint32_t MRT_KERNEL_TWO_LEVEL = 100u;    // internal kernel ids (TraceParams.kernel): one lane per ray,
 constexpr uint32_t MRT_KERNEL_TWO_LEVEL_PACKET = 101u; // one wave per 64-ray packet (coherent batches)
+constexpr uint32_t MRT_KERNEL_TWO_LEVEL_PERSISTENT = 102u; // resident waves, node / leaf phases (large incoherent batches)
 struct alignas(16) DevInstance {
 	float inv[12];      // world -> object, rows {m00 m01 m02 tx}: o' = M o + t, d' = M d (no renormalisation: t stays world-parameterised)
 	float basis[9];     // object -> world 3x3 (normals: normalize(basis n))

@@ -41,14 +41,21 @@ def _check(c, osc, name):
     assert int((osc.trace(grid)["prim_id"] >= 0).sum()) > 50
     cam = capi.camera_look((0, 0, -12), (0, 0, 1), 160, 120, 50.0)
     parity.assert_exact(c.cast_grid(cam, 160, 120), osc.trace(grid), f"{name} cast_grid")
+    # a batch large enough for the persistent form (resident waves, node / leaf phases, stack spill)
+    big = np.concatenate([inc, grid, inc[::-1], grid[::-1], inc])
+    want = osc.trace(big)
+    for flags in (capi.FLAG_COHERENT, 0):
+        parity.assert_exact(c.cast(big, flags=flags), want, f"{name} big flags={flags}")
+    b = c.cast(big, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT)
+    assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
 
 
-@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE])
-def test_two_level_scene_gives_the_oracles_hits(built, kernel):
-    """AUTO: the packet form for grids and batches flagged coherent, one lane per ray otherwise; KERNEL_LANE:
-    one lane per ray throughout."""
+@pytest.mark.parametrize("kernel,stack", [(capi.KERNEL_AUTO, 0), (capi.KERNEL_LANE, 0), (capi.KERNEL_AUTO, 4)])
+def test_two_level_scene_gives_the_oracles_hits(built, kernel, stack):
+    """AUTO: the packet form for grids and batches flagged coherent, one lane per ray otherwise (resident waves
+    for large batches; with 4 stack entries in LDS the rest spills to HBM); KERNEL_LANE: the plain lane kernel."""
     local, inst = _scene()
-    c = capi.Context(0, kernel=kernel)
+    c = capi.Context(0, kernel=kernel, stack_override=stack)
     c.upload_two_level_scene(local, inst)
     assert c.is_available()
     info = c.scene_info()
