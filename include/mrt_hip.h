@@ -297,7 +297,7 @@ int mrt_build_instanced_scene_device(mrt_ctx *ctx, const float *verts9, uint32_t
  * transform without renormalising its direction, so t stays world-parameterised.  Hit records:
  * prim_id = the FLAT id of raytracer_server.cpp:700-711 (the instance's running triangle offset +
  * the mesh-local index; the reference's TLAS path reports the local index, SURVEY.md section 0
- * item 3), hit_layers = the instance's mask (whole instances are skipped by the query mask),
+ * item 4), hit_layers = the instance's mask (whole instances are skipped by the query mask),
  * normal = normalize(basis * mesh-space normal), position on the world ray.  Every cast entry
  * point works on such a scene (one lane per ray); hit tokens do not (MRT_ERR_UNSUPPORTED).
  * verts9 / instances: host arrays.  Transforms must be invertible (MRT_ERR_INVALID).

@@ -4,7 +4,7 @@
 //   SceneTLAS::build_tlas / refit_tlas (src/accel/scene_tlas.h:140-196) BVH2 over the instances' world boxes
 // The flat ids follow RayTracerServer::_rebuild_scene (raytracer_server.cpp:700-711): an instance's
 // first triangle has the running triangle count of the instances registered before it (the reference's
-// own TLAS path reports mesh-local ids, SURVEY.md section 0 item 3; the flat id is what its callers index by).
+// own TLAS path reports mesh-local ids, SURVEY.md section 0 item 4; the flat id is what its callers index by).
 #include "../mrt_internal.h"
 
 #include <cmath>

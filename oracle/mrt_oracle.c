@@ -641,7 +641,7 @@ void orc_flatten_instances(const float *verts9, const orc_instance *inst, uint32
 /* Deliberate differences from the reference, shared with the HIP path:          */
 /*  - prim_id is the FLAT id of raytracer_server.cpp:700-711 (running triangle   */
 /*    offset of the instance + mesh-local index); SceneTLAS reports the local    */
-/*    index (SURVEY.md section 0 item 3), which its callers cannot resolve;      */
+/*    index (SURVEY.md section 0 item 4), which its callers cannot resolve;      */
 /*  - hit_layers is the instance's mask (raytracer_server.cpp:702-703) and whole */
 /*    instances are skipped by the query mask (tiny_bvh.h:3323-3324);            */
 /*  - an exact tie in t goes to the lower flat id (as in trace_one);             */
