@@ -133,15 +133,18 @@ __device__ __forceinline__ void packet_node_loop_asm(const DevNode *base, uint32
 
 template <int OCT, bool ANY_HIT>
 __device__ __forceinline__ void packet_traverse_asm(const TraceParams &p, const RayRegs &r, uint32_t sp,
-		float &best_t, float &best_u, float &best_v, uint32_t &best_slot)
+		float &best_t, float &best_u, float &best_v, uint32_t &best_slot,
+		// a BLAS of a two-level scene (two_level_kernel.h): its root, the instance's flat id base, the id of the
+		// best hit so far (in / out), and whether this lane sits the walk out (its world ray missed the instance)
+		uint32_t root = 0u, uint32_t id_base = 0u, uint32_t *best_id_io = nullptr, bool dead = false)
 {
 	const bool degenerate = r.t_min >= r.t_max;
-	float lim_t = degenerate ? -FLT_MAX : best_t;
+	float lim_t = (degenerate || dead) ? -FLT_MAX : best_t;
 	const float ix = safe_inv(r.dx), iy = safe_inv(r.dy), iz = safe_inv(r.dz);
 	const float nrx = -(r.ox * ix), nry = -(r.oy * iy), nrz = -(r.oz * iz);
 	const float4 *hot = reinterpret_cast<const float4 *>(p.tri_hot);
-	uint32_t best_id = 0xFFFFFFFFu;
-	uint32_t cur = 0; // root: always a wide node
+	uint32_t best_id = best_id_io ? *best_id_io : 0xFFFFFFFFu;
+	uint32_t cur = root; // always a wide node
 	uint32_t dopop = 0;
 	for (;;) {
 		packet_node_loop_asm<OCT>(p.nodes, cur, sp, dopop, ix, iy, iz, nrx, nry, nrz, r.t_min, lim_t);
@@ -175,7 +178,7 @@ __device__ __forceinline__ void packet_traverse_asm(const TraceParams &p, const 
 						const float v = dot3(r.dx, r.dy, r.dz, qvx, qvy, qvz) * inv_det;
 						if (!(v < 0.0f || u + v > 1.0f)) {
 							const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
-							const uint32_t id = __float_as_uint(q0.w);
+							const uint32_t id = id_base + __float_as_uint(q0.w);
 							if (!(t < r.t_min) && (t < lim_leaf || (t == lim_leaf && best_slot != 0xFFFFFFFFu && id < best_id))) {
 								best_t = t; best_u = u; best_v = v; best_slot = slot; best_id = id;
 								lim_t = lim_leaf = ANY_HIT ? -FLT_MAX : t;
@@ -189,6 +192,7 @@ __device__ __forceinline__ void packet_traverse_asm(const TraceParams &p, const 
 		if (ANY_HIT && __ballot(lim_t != -FLT_MAX) == 0ull) break;
 		dopop = 1;
 	}
+	if (best_id_io) *best_id_io = best_id;
 }
 
 template <bool ANY_HIT>

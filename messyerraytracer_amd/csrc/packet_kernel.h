@@ -25,19 +25,22 @@
 
 template <int OCT, bool ANY_HIT, bool COUNT>
 __device__ __forceinline__ void packet_traverse(const TraceParams &p, const RayRegs &r, uint32_t *stack,
-		float &best_t, float &best_u, float &best_v, uint32_t &best_slot, uint32_t &n_nodes, uint32_t &n_tris, uint32_t &n_dead)
+		float &best_t, float &best_u, float &best_v, uint32_t &best_slot, uint32_t &n_nodes, uint32_t &n_tris, uint32_t &n_dead,
+		// a BLAS of a two-level scene (two_level_kernel.h): its root, the instance's flat id base, the id of the
+		// best hit so far (in / out), and whether this lane sits the walk out (its world ray missed the instance)
+		uint32_t root = 0u, uint32_t id_base = 0u, uint32_t *best_id_io = nullptr, bool dead = false)
 {
 	const bool degenerate = r.t_min >= r.t_max; // glsl:214-222: a miss with t = t_max
 	// a lane that must not take part any more gets an empty interval: no box test can pass
-	float lim_t = degenerate ? -FLT_MAX : best_t;
+	float lim_t = (degenerate || dead) ? -FLT_MAX : best_t;
 	const float ix = safe_inv(r.dx), iy = safe_inv(r.dy), iz = safe_inv(r.dz);
 	const float nrx = -(r.ox * ix), nry = -(r.oy * iy), nrz = -(r.oz * iz);
 	const float4 *nodes = reinterpret_cast<const float4 *>(p.nodes);
 	const float4 *hot = reinterpret_cast<const float4 *>(p.tri_hot);
-	uint32_t best_id = 0xFFFFFFFFu;
+	uint32_t best_id = best_id_io ? *best_id_io : 0xFFFFFFFFu;
 	constexpr bool NX = (OCT & 1) != 0, NY = (OCT & 2) != 0, NZ = (OCT & 4) != 0; // inv < 0 on that axis
 	uint32_t sp = 0;   // wave-uniform
-	uint32_t cur = 0;  // wave-uniform: the root is always a wide node
+	uint32_t cur = root; // wave-uniform: always a wide node
 	bool popped = false;
 	unsigned long long own_bits = 0ull; // bit k: this lane's own ray hit the box of stack entry k
 	bool own = true;                    // ... of the node in `cur` (used when it is a leaf)
@@ -117,7 +120,7 @@ __device__ __forceinline__ void packet_traverse(const TraceParams &p, const RayR
 							if (!(v < 0.0f || u + v > 1.0f)) {
 								const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
 								// lim_t == best_t for live lanes; exact ties go to the lower triangle id
-								const uint32_t id = __float_as_uint(q0.w);
+								const uint32_t id = id_base + __float_as_uint(q0.w);
 								if (!(t < r.t_min) && (t < lim_leaf || (t == lim_leaf && best_slot != 0xFFFFFFFFu && id < best_id))) {
 									best_t = t; best_u = u; best_v = v; best_slot = slot; best_id = id;
 									lim_t = lim_leaf = ANY_HIT ? -FLT_MAX : t; // any-hit: this lane is done
@@ -135,6 +138,7 @@ __device__ __forceinline__ void packet_traverse(const TraceParams &p, const RayR
 		own = ((own_bits >> sp) & 1ull) != 0ull;
 		popped = true;
 	}
+	if (best_id_io) *best_id_io = best_id;
 }
 
 template <bool ANY_HIT, bool COUNT>

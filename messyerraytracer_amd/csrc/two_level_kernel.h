@@ -150,42 +150,43 @@ __global__ __launch_bounds__(MRT_WG) void trace_two_level_kernel(const TracePara
 }
 
 // ---- the same walk for coherent batches: one wave = one packet of 64 rays --------------------------
-// The packet kernel of packet_kernel.h (generic octant form) extended over both levels: the node
-// index, the stack (one LDS dword per entry per wave) and the level are wave-uniform; nodes,
-// triangles and DevInstance rows are fetched once per wave through the scalar cache; a child or an
-// instance is entered when ANY lane's box test passed.  As there, a lane accepts hits only where its
-// own ray went: it carries an ownership bit per stack entry, and a lane whose world ray missed an
-// instance's box walks that instance's BLAS with an empty interval (no box test can pass), so every
-// lane reports exactly what the one-ray walk above reports.
+// The TLAS is walked as packet_kernel.h walks a tree (generic octant form): node index and stack
+// (one LDS dword per entry per wave) wave-uniform, nodes and DevInstance rows fetched once per wave
+// through the scalar cache, a child or an instance entered when ANY lane's box test passed, one
+// ownership bit per lane and stack entry.  Entering an instance, every lane takes its ray to mesh
+// space and the wave walks the BLAS with the flat-scene packet walkers, started at the BLAS root with
+// the instance's id base: packet_traverse_asm (hand-written node loop, octant-specialised) when the
+// mesh-space rays of the lanes that take part share one octant, packet_traverse<8> otherwise.  A lane
+// whose world ray missed the instance's box sits that walk out with an empty interval (no box test
+// can pass), so every lane reports exactly what the one-ray walk above reports.
 template <bool ANY_HIT>
 __global__ __launch_bounds__(MRT_WG) void trace_two_level_packet_kernel(const TraceParams p)
 {
-	__shared__ uint32_t wave_stack[MRT_WG / MRT_WAVE][MRT_PACKET_STACK];
+	__shared__ __attribute__((aligned(16))) uint32_t blas_stack[MRT_WG / MRT_WAVE][(MRT_PACKET_STACK + 1) * 4]; // 16-byte entries (packet_asm_kernel.h)
+	__shared__ uint32_t tlas_stack[MRT_WG / MRT_WAVE][MRT_PACKET_STACK];
 	if (skip_launch(p)) return;
 	uint64_t ray_idx = 0; uint32_t px = 0, py = 0;
 	if (!lane_ray_index(p, blockIdx.x, ray_idx, px, py)) return; // exited lanes drop out of every ballot
 	RayRegs r;
 	load_ray(p, ray_idx, px, py, r);
-	uint32_t *stack = wave_stack[threadIdx.x / MRT_WAVE];
+	uint32_t *stack = tlas_stack[threadIdx.x / MRT_WAVE];
+	uint32_t *bstack = blas_stack[threadIdx.x / MRT_WAVE];
 
 	float best_t = r.t_max, best_u = 0.0f, best_v = 0.0f;
 	uint32_t best_slot = 0xFFFFFFFFu, best_id = 0xFFFFFFFFu, best_inst = 0u;
 	const bool degenerate = r.t_min >= r.t_max;
 	float lim_t = degenerate ? -FLT_MAX : best_t; // empty interval: this lane takes no part
-	float ox = r.ox, oy = r.oy, oz = r.oz, dx = r.dx, dy = r.dy, dz = r.dz;
-	float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
-	float nrx = -(ox * ix), nry = -(oy * iy), nrz = -(oz * iz);
+	const float ix = safe_inv(r.dx), iy = safe_inv(r.dy), iz = safe_inv(r.dz);
+	const float nrx = -(r.ox * ix), nry = -(r.oy * iy), nrz = -(r.oz * iz);
 	const float4 *nodes = reinterpret_cast<const float4 *>(p.nodes);
-	const float4 *hot = reinterpret_cast<const float4 *>(p.tri_hot);
 	const float4 *inst = reinterpret_cast<const float4 *>(p.instances);
-	uint32_t sp = 0, cur = 0, id_base = 0u, cur_inst = 0u; // wave-uniform
-	bool in_blas = false;                                  // wave-uniform
+	uint32_t sp = 0, cur = 0; // wave-uniform
 	unsigned long long own_bits = 0ull;
 	bool own = true;
 
 	for (;;) {
 		cur = __builtin_amdgcn_readfirstlane(cur);
-		if (cur < kInstanceReturn) {
+		if (cur < kSentinel) {
 			const float4 *n = nodes + (size_t)cur * 4u; // uniform address: scalar loads
 			const float4 a = n[0], b = n[1], c = n[2], d = n[3];
 			const float l0x = fma_(a.x, ix, nrx), l1x = fma_(b.x, ix, nrx);
@@ -212,13 +213,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_two_level_packet_kernel(const Tr
 			}
 			if (ml != 0ull) { cur = lref; own = hl; continue; }
 			if (mr != 0ull) { cur = rref; own = hr; continue; }
-		} else if (cur == kInstanceReturn) { // the BLAS is done: back to the world ray and the lane's own interval
-			ox = r.ox; oy = r.oy; oz = r.oz; dx = r.dx; dy = r.dy; dz = r.dz;
-			ix = safe_inv(dx); iy = safe_inv(dy); iz = safe_inv(dz);
-			nrx = -(ox * ix); nry = -(oy * iy); nrz = -(oz * iz);
-			lim_t = (degenerate || (ANY_HIT && best_slot != 0xFFFFFFFFu)) ? -FLT_MAX : best_t;
-			in_blas = false;
-		} else if (!in_blas) { // TLAS leaf: a run of instances, one at a time
+		} else { // TLAS leaf: a run of instances, one at a time
 			const uint32_t slot0 = cur & 0x7FFFFFFFu;
 			const float4 *row = inst + (size_t)slot0 * 8u; // uniform address
 			const float4 m0 = row[0], m1 = row[1], m2 = row[2], meta = row[5];
@@ -228,57 +223,41 @@ __global__ __launch_bounds__(MRT_WG) void trace_two_level_packet_kernel(const Tr
 				own_bits = own ? (own_bits | (1ull << sp)) : (own_bits & ~(1ull << sp));
 				sp++;
 			}
-			if ((__float_as_uint(meta.w) & p.query_mask) != 0u) {
-				ox = fma_(m0.x, r.ox, fma_(m0.y, r.oy, fma_(m0.z, r.oz, m0.w)));
-				oy = fma_(m1.x, r.ox, fma_(m1.y, r.oy, fma_(m1.z, r.oz, m1.w)));
-				oz = fma_(m2.x, r.ox, fma_(m2.y, r.oy, fma_(m2.z, r.oz, m2.w)));
-				dx = fma_(m0.x, r.dx, fma_(m0.y, r.dy, m0.z * r.dz));
-				dy = fma_(m1.x, r.dx, fma_(m1.y, r.dy, m1.z * r.dz));
-				dz = fma_(m2.x, r.dx, fma_(m2.y, r.dy, m2.z * r.dz));
-				ix = safe_inv(dx); iy = safe_inv(dy); iz = safe_inv(dz);
-				nrx = -(ox * ix); nry = -(oy * iy); nrz = -(oz * iz);
-				if (!own) lim_t = -FLT_MAX; // this lane's world ray missed the instance's box
-				stack[sp] = kInstanceReturn; sp++;
-				in_blas = true; cur_inst = slot0;
-				id_base = __float_as_uint(meta.z);
-				cur = __float_as_uint(meta.y);
-				continue;
-			}
-		} else { // BLAS leaf: every lane whose own (mesh-space) ray hit the leaf's box tests its triangles
-			float lim_leaf = own ? lim_t : -FLT_MAX;
-			uint32_t slot = cur & 0x7FFFFFFFu;
-			bool last;
-			do {
-				const float4 *t3 = hot + (size_t)slot * 3u; // uniform address
-				const float4 q0 = t3[0], q1 = t3[1], q2 = t3[2];
-				last = (__float_as_uint(q2.w) & kLastInLeaf) != 0u;
-				const float pvx = fma_(dy, q2.z, -(dz * q2.y));
-				const float pvy = fma_(dz, q2.x, -(dx * q2.z));
-				const float pvz = fma_(dx, q2.y, -(dy * q2.x));
-				const float det = dot3(q1.x, q1.y, q1.z, pvx, pvy, pvz);
-				if (!(__builtin_fabsf(det) < 1e-8f)) {
-					const float inv_det = 1.0f / det;
-					const float tvx = ox - q0.x, tvy = oy - q0.y, tvz = oz - q0.z;
-					const float u = dot3(tvx, tvy, tvz, pvx, pvy, pvz) * inv_det;
-					if (!(u < 0.0f || u > 1.0f)) {
-						const float qvx = fma_(tvy, q1.z, -(tvz * q1.y));
-						const float qvy = fma_(tvz, q1.x, -(tvx * q1.z));
-						const float qvz = fma_(tvx, q1.y, -(tvy * q1.x));
-						const float v = dot3(dx, dy, dz, qvx, qvy, qvz) * inv_det;
-						if (!(v < 0.0f || u + v > 1.0f)) {
-							const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
-							const uint32_t id = id_base + __float_as_uint(q0.w);
-							if (!(t < r.t_min) && (t < lim_leaf || (t == lim_leaf && best_slot != 0xFFFFFFFFu && id < best_id))) {
-								best_t = t; best_u = u; best_v = v; best_slot = slot; best_id = id; best_inst = cur_inst;
-								lim_t = lim_leaf = ANY_HIT ? -FLT_MAX : t;
-							}
-						}
-					}
+			// lanes that sit this instance out: their world ray missed its box, or they are done
+			const bool dead = !own || lim_t == -FLT_MAX;
+			const unsigned long long alive = __ballot(!dead);
+			if ((__float_as_uint(meta.w) & p.query_mask) != 0u && alive != 0ull) {
+				RayRegs ro;
+				ro.ox = fma_(m0.x, r.ox, fma_(m0.y, r.oy, fma_(m0.z, r.oz, m0.w)));
+				ro.oy = fma_(m1.x, r.ox, fma_(m1.y, r.oy, fma_(m1.z, r.oz, m1.w)));
+				ro.oz = fma_(m2.x, r.ox, fma_(m2.y, r.oy, fma_(m2.z, r.oz, m2.w)));
+				ro.dx = fma_(m0.x, r.dx, fma_(m0.y, r.dy, m0.z * r.dz));
+				ro.dy = fma_(m1.x, r.dx, fma_(m1.y, r.dy, m1.z * r.dz));
+				ro.dz = fma_(m2.x, r.dx, fma_(m2.y, r.dy, m2.z * r.dz));
+				ro.t_min = r.t_min; ro.t_max = r.t_max;
+				const uint32_t root = __builtin_amdgcn_readfirstlane(__float_as_uint(meta.y));
+				const uint32_t id_base = __builtin_amdgcn_readfirstlane(__float_as_uint(meta.z));
+				const uint32_t before_id = best_id; const float before_t = best_t;
+				// octant of the mesh-space rays that take part
+				const unsigned long long sx = __ballot(!dead && safe_inv(ro.dx) < 0.0f), sy = __ballot(!dead && safe_inv(ro.dy) < 0.0f),
+						sz = __ballot(!dead && safe_inv(ro.dz) < 0.0f);
+				const bool uniform = (sx == 0ull || sx == alive) && (sy == 0ull || sy == alive) && (sz == 0ull || sz == alive);
+				const int oct = uniform ? ((sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0)) : 8;
+				if (oct == 8) {
+					uint32_t nn = 0, nt = 0, nd = 0;
+					packet_traverse<8, ANY_HIT, false>(p, ro, bstack, best_t, best_u, best_v, best_slot, nn, nt, nd, root, id_base, &best_id, dead);
+				} else {
+					*(volatile uint32_t *)&bstack[0] = kSentinel;
+					const uint32_t bsp = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(bstack + 4);
+#define MRT_PKTB(O) case O: packet_traverse_asm<O, ANY_HIT>(p, ro, bsp, best_t, best_u, best_v, best_slot, root, id_base, &best_id, dead); break;
+					switch (oct) { MRT_PKTB(0) MRT_PKTB(1) MRT_PKTB(2) MRT_PKTB(3) MRT_PKTB(4) MRT_PKTB(5) MRT_PKTB(6) MRT_PKTB(7) }
+#undef MRT_PKTB
 				}
-				slot++;
-			} while (!last);
-			// any-hit: done when every lane is degenerate or has its answer (lanes outside this instance still wait)
-			if (ANY_HIT && __ballot(!degenerate && best_slot == 0xFFFFFFFFu) == 0ull) break;
+				if (best_id != before_id || best_t != before_t) best_inst = slot0;
+				if (!degenerate) lim_t = (ANY_HIT && best_slot != 0xFFFFFFFFu) ? -FLT_MAX : best_t;
+				// any-hit: done when every lane is degenerate or has its answer
+				if (ANY_HIT && __ballot(lim_t != -FLT_MAX) == 0ull) break;
+			}
 		}
 		if (sp == 0) break;
 		sp--; cur = stack[sp];
