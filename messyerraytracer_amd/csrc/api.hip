@@ -24,6 +24,7 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t stream);
 hipError_t launch_expand_tokens(const TraceParams &p, const uint32_t *tokens, hipStream_t stream);
 hipError_t launch_offset_refs(DevNode *dst, const DevNode *src, uint32_t n, uint32_t node_base, uint32_t tri_base, void *stream);
+hipError_t launch_offset_refs8(Dev8Node *dst, const Dev8Node *src, uint32_t n, uint32_t node_base, uint32_t tri_base, void *stream);
 hipError_t launch_flatten_instances(const float *d_verts9, const mrt_instance *d_instances, const uint32_t *d_first_out,
 		uint32_t n_instances, uint32_t max_tris_per_instance, mrt_tri64 *d_out, void *stream);
 hipError_t launch_morton_keys(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t *keys, uint32_t *index, hipStream_t stream);
@@ -221,7 +222,7 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 		ovf = (uint32_t *)ctx->overflow.ptr;
 	}
 	p.kernel = wide8 ? MRT_KERNEL_LANE8_PERSISTENT : (wide4 ? MRT_KERNEL_LANE4_PERSISTENT : MRT_KERNEL_LANE_PERSISTENT);
-	if (ctx->two_level) p.kernel = mrt::MRT_KERNEL_TWO_LEVEL_PERSISTENT; // the 2-wide walk over both levels (need = ctx->depth)
+	if (ctx->two_level) p.kernel = wide8 ? mrt::MRT_KERNEL_TWO_LEVEL_PERSISTENT8 : mrt::MRT_KERNEL_TWO_LEVEL_PERSISTENT; // need = stack8 (= depth8) / depth
 	// eight ray counters (one per region of the batch), 128 bytes apart
 	unsigned long long *next_ray = ctx->d_counters + 16 + 1026;
 	HIP_TRY(ctx, hipMemsetAsync(next_ray, 0, 128 * sizeof(unsigned long long), ctx->stream));
@@ -669,13 +670,21 @@ static int build_blases_on_device(mrt_ctx *ctx, mrt::TwoLevelHost *h, const floa
 		hipError_t e = hipMemcpy(staged, tris.data(), (size_t)bl.n_tris * sizeof(mrt_tri64), hipMemcpyHostToDevice);
 		if (e != hipSuccess) { rc = fail(ctx, MRT_ERR_HIP, hipGetErrorString(e)); break; }
 		mrt::DeviceBuildResult b;
-		rc = mrt::device_build_lbvh(staged, bl.n_tris, false, false, false, (void *)ctx->stream, &b, ctx->err, sizeof(ctx->err));
+		rc = mrt::device_build_lbvh(staged, bl.n_tris, false, h->wide8, false, (void *)ctx->stream, &b, ctx->err, sizeof(ctx->err));
 		if (rc) break;
 		e = mrt::launch_offset_refs(ctx->d_nodes + bl.root, b.nodes, b.n_nodes, bl.root, tri_base, (void *)ctx->stream);
+		if (h->wide8 && !(b.nodes8 && b.leaf_box)) h->wide8 = false; // a mesh whose boxes fit no grid: the scene goes without the 8-wide layout
+		if (h->wide8) {
+			if (e == hipSuccess) e = mrt::launch_offset_refs8(ctx->d_nodes8 + bl.root8, b.nodes8, b.n_nodes, bl.root8, tri_base, (void *)ctx->stream);
+			if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_leaf_box + (size_t)tri_base * 8, b.leaf_box, (size_t)bl.n_tris * 32, hipMemcpyDeviceToDevice, ctx->stream);
+			bl.stack8 = b.stack8;
+		}
 		if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_hot + tri_base, b.hot, (size_t)bl.n_tris * sizeof(mrt::TriHot), hipMemcpyDeviceToDevice, ctx->stream);
 		if (e == hipSuccess) e = hipMemcpyAsync(ctx->d_cold + tri_base, b.cold, (size_t)bl.n_tris * sizeof(mrt::TriCold), hipMemcpyDeviceToDevice, ctx->stream);
 		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
 		(void)hipFree(b.nodes); (void)hipFree(b.hot); (void)hipFree(b.cold);
+		if (b.nodes8) (void)hipFree(b.nodes8);
+		if (b.leaf_box) (void)hipFree(b.leaf_box);
 		if (e != hipSuccess) { rc = fail(ctx, MRT_ERR_HIP, hipGetErrorString(e)); break; }
 		if (b.n_nodes != bl.n_tris - 1u) { rc = fail(ctx, MRT_ERR_BAD_BVH, "two-level scene: unexpected BLAS size"); break; }
 		bl.depth = b.depth;
@@ -714,6 +723,12 @@ int mrt_upload_two_level_scene(mrt_ctx *ctx, const float *verts9, uint32_t n_mes
 		drop(); free_scene(ctx);
 		return fail(ctx, MRT_ERR_OOM, "scene does not fit in device memory");
 	}
+	if (on_device) { h->wide8 = true; h->n_nodes8 = h->n_nodes - h->tlas_cap; } // wanted; build_blases_on_device takes it back if a mesh has none
+	if (h->wide8 && (hipMalloc(&ctx->d_nodes8, (size_t)h->n_nodes8 * sizeof(mrt::Dev8Node)) != hipSuccess ||
+			hipMalloc(&ctx->d_leaf_box, (size_t)h->n_tris * 32) != hipSuccess)) { // an optional layout: go without it
+		if (ctx->d_nodes8) (void)hipFree(ctx->d_nodes8);
+		ctx->d_nodes8 = nullptr; ctx->d_leaf_box = nullptr; h->wide8 = false;
+	}
 	if (on_device) {
 		hipEvent_t e0, e1;
 		HIP_TRY(ctx, hipEventCreate(&e0)); HIP_TRY(ctx, hipEventCreate(&e1));
@@ -732,10 +747,18 @@ int mrt_upload_two_level_scene(mrt_ctx *ctx, const float *verts9, uint32_t n_mes
 		e = hipMemcpy(ctx->d_nodes, h->nodes, (size_t)h->n_nodes * sizeof(mrt::DevNode), hipMemcpyHostToDevice);
 		if (e == hipSuccess) e = hipMemcpy(ctx->d_hot, h->hot, (size_t)h->n_tris * sizeof(mrt::TriHot), hipMemcpyHostToDevice);
 		if (e == hipSuccess) e = hipMemcpy(ctx->d_cold, h->cold, (size_t)h->n_tris * sizeof(mrt::TriCold), hipMemcpyHostToDevice);
+		if (e == hipSuccess && h->wide8) e = hipMemcpy(ctx->d_nodes8, h->nodes8, (size_t)h->n_nodes8 * sizeof(mrt::Dev8Node), hipMemcpyHostToDevice);
+		if (e == hipSuccess && h->wide8) e = hipMemcpy(ctx->d_leaf_box, h->leaf_box, (size_t)h->n_tris * 32, hipMemcpyHostToDevice);
+	}
+	if (!h->wide8 && ctx->d_nodes8) { // taken back during the device builds
+		(void)hipFree(ctx->d_nodes8); (void)hipFree(ctx->d_leaf_box);
+		ctx->d_nodes8 = nullptr; ctx->d_leaf_box = nullptr;
 	}
 	if (e == hipSuccess) e = hipMemcpy(ctx->d_instances, h->inst, (size_t)h->n_inst * sizeof(mrt::DevInstance), hipMemcpyHostToDevice);
 	if (e != hipSuccess) { drop(); free_scene(ctx); return fail(ctx, MRT_ERR_HIP, hipGetErrorString(e)); }
 	std::free(h->hot); std::free(h->cold); h->hot = nullptr; h->cold = nullptr; // the device has them; a refit only needs nodes + instances
+	std::free(h->nodes8); std::free(h->leaf_box); h->nodes8 = nullptr; h->leaf_box = nullptr;
+	ctx->n_nodes8 = h->wide8 ? h->n_nodes8 : 0; ctx->stack8 = h->wide8 ? h->depth8 : 0;
 	ctx->two_level = h;
 	ctx->n_nodes = h->n_nodes; ctx->n_tris = h->n_tris; ctx->depth = h->depth;
 	ctx->stack_depth = ((h->depth + 7u) / 8u) * 8u;
@@ -765,7 +788,7 @@ int mrt_update_instances(mrt_ctx *ctx, const mrt_instance *instances, uint32_t n
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	HIP_TRY(ctx, hipMemcpy(ctx->d_nodes, h->nodes, (size_t)h->n_tlas_nodes * sizeof(mrt::DevNode), hipMemcpyHostToDevice));
 	HIP_TRY(ctx, hipMemcpy(ctx->d_instances, h->inst, (size_t)h->n_inst * sizeof(mrt::DevInstance), hipMemcpyHostToDevice));
-	ctx->depth = h->depth;
+	ctx->depth = h->depth; ctx->stack8 = h->wide8 ? h->depth8 : 0;
 	ctx->stack_depth = ((h->depth + 7u) / 8u) * 8u;
 	if (ctx->stack_depth < 8) ctx->stack_depth = 8;
 	for (int c = 0; c < 3; c++) {

@@ -428,7 +428,27 @@ __global__ __launch_bounds__(LBVH_WG) void offset_refs_kernel(DevNode *dst, cons
 	dst[i] = g;
 }
 
+// ... and its 8-wide layout (one Dev8Node per binary node, at the binary node's own offset)
+__global__ __launch_bounds__(LBVH_WG) void offset_refs8_kernel(Dev8Node *dst, const Dev8Node *src, uint32_t n, uint32_t node_base, uint32_t tri_base)
+{
+	const uint32_t i = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (i >= n) return;
+	Dev8Node g = src[i];
+	for (int c = 0; c < 8; c++) {
+		const uint32_t ref = g.ref[c];
+		g.ref[c] = ref < kSentinel ? ref + node_base : (ref >= kLeafBit ? (kLeafBit | ((ref & 0x7FFFFFFFu) + tri_base)) : ref);
+	}
+	dst[i] = g;
+}
+
 } // namespace
+
+hipError_t launch_offset_refs8(Dev8Node *dst, const Dev8Node *src, uint32_t n, uint32_t node_base, uint32_t tri_base, void *stream)
+{
+	if (n == 0) return hipSuccess;
+	hipLaunchKernelGGL(offset_refs8_kernel, dim3((n + LBVH_WG - 1) / LBVH_WG), dim3(LBVH_WG), 0, (hipStream_t)stream, dst, src, n, node_base, tri_base);
+	return hipGetLastError();
+}
 
 hipError_t launch_offset_refs(DevNode *dst, const DevNode *src, uint32_t n, uint32_t node_base, uint32_t tri_base, void *stream)
 {

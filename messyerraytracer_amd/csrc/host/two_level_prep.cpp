@@ -21,6 +21,7 @@ void free_two_level(TwoLevelHost *h)
 {
 	if (!h) return;
 	std::free(h->nodes); std::free(h->hot); std::free(h->cold); std::free(h->inst); std::free(h->blas); std::free(h->inst_blas);
+	std::free(h->nodes8); std::free(h->leaf_box);
 	*h = TwoLevelHost();
 }
 
@@ -118,7 +119,7 @@ int refit_two_level(TwoLevelHost *h, const mrt_instance *instances, uint32_t n, 
 		std::memset(&d, 0, sizeof(d));
 		if (!invert_affine(in.basis, in.origin, d.inv)) return fail_(err, err_len, MRT_ERR_INVALID, "two-level scene: singular instance transform");
 		for (int k = 0; k < 9; k++) d.basis[k] = in.basis[k];
-		d.root = b.root; d.id_base = (uint32_t)id_base; d.layers = in.layers; d.index = i;
+		d.root = b.root; d.root8 = b.root8; d.id_base = (uint32_t)id_base; d.layers = in.layers; d.index = i;
 		id_base += in.n_tris;
 		world_box(b.lo, b.hi, in.basis, in.origin, &lo[(size_t)3 * i], &hi[(size_t)3 * i]);
 	}
@@ -126,8 +127,11 @@ int refit_two_level(TwoLevelHost *h, const mrt_instance *instances, uint32_t n, 
 	int rc = build_over_boxes(lo.data(), hi.data(), n, &t, err, err_len);
 	if (rc) return rc;
 	if (t.n_nodes > h->tlas_cap) { free_scene_host(t); return fail_(err, err_len, MRT_ERR_BAD_BVH, "two-level scene: TLAS larger than its reserved range"); }
-	uint32_t max_blas = 0;
-	for (uint32_t k = 0; k < h->n_blas; k++) if (h->blas[k].depth > max_blas) max_blas = h->blas[k].depth;
+	uint32_t max_blas = 0, max_blas8 = 0;
+	for (uint32_t k = 0; k < h->n_blas; k++) {
+		if (h->blas[k].depth > max_blas) max_blas = h->blas[k].depth;
+		if (h->blas[k].stack8 > max_blas8) max_blas8 = h->blas[k].stack8;
+	}
 	// TLAS nodes keep their indices (the TLAS occupies the front of the array); leaf refs already are instance slots
 	std::memcpy(h->nodes, t.nodes, (size_t)t.n_nodes * sizeof(DevNode));
 	h->n_tlas_nodes = t.n_nodes;
@@ -137,6 +141,7 @@ int refit_two_level(TwoLevelHost *h, const mrt_instance *instances, uint32_t n, 
 	}
 	// pending entries: TLAS path (t.depth incl. sentinel) + the rest of a TLAS leaf + the return marker + a BLAS path
 	h->depth = t.depth + 2u + max_blas;
+	h->depth8 = t.depth + 2u + max_blas8;
 	free_scene_host(t);
 	return MRT_OK;
 }
@@ -175,7 +180,7 @@ int prepare_two_level(const float *verts9, uint32_t n_mesh_tris, const mrt_insta
 		uint64_t n_nodes = tlas_cap;
 		for (auto &b : blas) {
 			if (b.n_tris < 2) return fail_(err, err_len, MRT_ERR_UNSUPPORTED, "two-level scene: a mesh of one triangle needs the host builder");
-			b.root = (uint32_t)n_nodes; n_nodes += b.n_tris - 1u;
+			b.root = (uint32_t)n_nodes; b.root8 = b.root - tlas_cap; n_nodes += b.n_tris - 1u; // the 8-wide node of a binary node sits at the same offset
 		}
 		if (n_nodes >= kInstanceReturn) return fail_(err, err_len, MRT_ERR_UNSUPPORTED, "two-level scene: too many nodes");
 		h.nodes = (DevNode *)std::calloc((size_t)tlas_cap, sizeof(DevNode));
@@ -206,6 +211,7 @@ int prepare_two_level(const float *verts9, uint32_t n_mesh_tris, const mrt_insta
 		std::vector<uint32_t> prim(nt);
 		uint32_t used = 0;
 		if ((rc = mrt_bvh2_build(v4.data(), nt, nodes.data(), prim.data(), &used, n_threads))) { cleanup(); return fail_(err, err_len, rc, "two-level scene: BLAS build failed"); }
+		built[k].want8 = true;
 		if ((rc = prepare_scene(tris.data(), nt, nodes.data(), used, prim.data(), &built[k], err, err_len))) { cleanup(); return rc; }
 		blas[k].depth = built[k].depth;
 		for (int c = 0; c < 3; c++) { blas[k].lo[c] = built[k].bounds_lo[c]; blas[k].hi[c] = built[k].bounds_hi[c]; }
@@ -222,7 +228,17 @@ int prepare_two_level(const float *verts9, uint32_t n_mesh_tris, const mrt_insta
 	if (!h.nodes || !h.hot || !h.cold || !h.inst || !h.blas || !h.inst_blas) { cleanup(); free_two_level(&h); return fail_(err, err_len, MRT_ERR_OOM, "two-level scene: out of host memory"); }
 	h.n_nodes = (uint32_t)n_nodes; h.tlas_cap = tlas_cap; h.n_tris = (uint32_t)unique_tris; h.n_inst = n; h.n_blas = (uint32_t)blas.size();
 	h.flat_tris = flat;
-	uint32_t node_base = tlas_cap, tri_base = 0;
+	// the 8-wide layout goes along if every BLAS has it (a non-finite box leaves a mesh without one)
+	uint64_t n8 = 0;
+	bool all8 = true;
+	for (size_t k = 0; k < blas.size(); k++) { all8 = all8 && built[k].nodes8 && built[k].leaf_box; n8 += built[k].n_nodes8; }
+	if (all8 && n8 < kInstanceReturn) {
+		h.nodes8 = (Dev8Node *)std::malloc((size_t)n8 * sizeof(Dev8Node));
+		h.leaf_box = (float *)std::malloc((size_t)unique_tris * 8 * sizeof(float));
+		if (h.nodes8 && h.leaf_box) { h.wide8 = true; h.n_nodes8 = (uint32_t)n8; }
+		else { std::free(h.nodes8); std::free(h.leaf_box); h.nodes8 = nullptr; h.leaf_box = nullptr; }
+	}
+	uint32_t node_base = tlas_cap, tri_base = 0, base8 = 0;
 	for (size_t k = 0; k < blas.size(); k++) { // concatenate, making node and leaf refs global
 		const DeviceSceneHost &s = built[k];
 		auto fix = [&](uint32_t ref) { return ref < kSentinel ? ref + node_base : (ref >= kLeafBit ? (kLeafBit | ((ref & 0x7FFFFFFFu) + tri_base)) : ref); };
@@ -233,6 +249,17 @@ int prepare_two_level(const float *verts9, uint32_t n_mesh_tris, const mrt_insta
 		}
 		std::memcpy(h.hot + tri_base, s.hot, (size_t)s.n_tris * sizeof(TriHot));
 		std::memcpy(h.cold + tri_base, s.cold, (size_t)s.n_tris * sizeof(TriCold));
+		if (h.wide8) {
+			auto fix8 = [&](uint32_t ref) { return ref < kSentinel ? ref + base8 : (ref >= kLeafBit ? (kLeafBit | ((ref & 0x7FFFFFFFu) + tri_base)) : ref); };
+			for (uint32_t w = 0; w < s.n_nodes8; w++) {
+				Dev8Node g = s.nodes8[w];
+				for (int c = 0; c < 8; c++) g.ref[c] = fix8(g.ref[c]);
+				h.nodes8[base8 + w] = g;
+			}
+			std::memcpy(h.leaf_box + (size_t)tri_base * 8, s.leaf_box, (size_t)s.n_tris * 8 * sizeof(float));
+			blas[k].root8 = base8; blas[k].stack8 = s.stack8;
+			base8 += s.n_nodes8;
+		}
 		blas[k].root = node_base;
 		node_base += s.n_nodes; tri_base += s.n_tris;
 	}

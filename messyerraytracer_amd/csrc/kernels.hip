@@ -583,7 +583,10 @@ hipError_t launch_trace_persistent(const TraceParams &p, unsigned long long *nex
 	const size_t lds = (size_t)(MRT_WG / MRT_WAVE) * lds_depth * MRT_WAVE * sizeof(uint32_t);
 	const bool wide8 = p.kernel == MRT_KERNEL_LANE8_PERSISTENT && p.nodes8 != nullptr;
 	const bool wide4 = p.kernel == MRT_KERNEL_LANE4_PERSISTENT && p.nodes4 != nullptr;
-	if (p.kernel == MRT_KERNEL_TWO_LEVEL_PERSISTENT) {
+	if (p.kernel == MRT_KERNEL_TWO_LEVEL_PERSISTENT8 && p.nodes8 != nullptr && p.leaf_box != nullptr) {
+		if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true, 8, true>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+		else hipLaunchKernelGGL((trace_lane_persistent_kernel<false, 8, true>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+	} else if (p.kernel == MRT_KERNEL_TWO_LEVEL_PERSISTENT || p.kernel == MRT_KERNEL_TWO_LEVEL_PERSISTENT8) {
 		if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true, 2, true>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
 		else hipLaunchKernelGGL((trace_lane_persistent_kernel<false, 2, true>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
 	} else if (wide8) {

@@ -54,13 +54,14 @@ struct PersistParams {
 // byte k of a packed word as a float (v_cvt_f32_ubyteK)
 __device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }
 
-// TL: a two-level scene (two_level_kernel.h; WIDTH 2 only): p.nodes holds the TLAS and every BLAS, a TLAS leaf
-// is a run of DevInstance rows, a lane inside an instance walks with its mesh-space ray and the marker
-// kInstanceReturn on its stack takes it back to the world ray.
+// TL: a two-level scene (two_level_kernel.h): p.nodes holds the TLAS and every BLAS, a TLAS leaf is a run of
+// DevInstance rows, a lane inside an instance walks with its mesh-space ray and the marker kInstanceReturn on
+// its stack takes it back to the world ray.  WIDTH 2: both levels 2-wide.  WIDTH 8: the TLAS 2-wide, every
+// BLAS in the 8-wide compressed layout (p.nodes8, p.leaf_box; DevInstance::root8).
 template <bool ANY_HIT, int WIDTH, bool TL = false> // WIDTH: children per node step = 2 (DevNode), 4 (Dev4Node) or 8 (Dev8Node)
 __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent_kernel(const TraceParams p, const PersistParams q)
 {
-	static_assert(!TL || WIDTH == 2, "two-level scenes are walked 2-wide");
+	static_assert(!TL || WIDTH == 2 || WIDTH == 8, "two-level scenes: 2-wide, or 8-wide inside the instances (the TLAS is always 2-wide)");
 	constexpr uint32_t kNode = TL ? kInstanceReturn : kSentinel; // refs below this are inner nodes
 	extern __shared__ uint32_t lds_stack[];
 	if (skip_launch(p)) return;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 					in_blas = false;
 					cur = pop();
 				}
-				if (WIDTH == 8 && cur < kSentinel) { // 8-wide compressed node: one 128-byte line, 96 bytes read
+				if (WIDTH == 8 && (!TL || in_blas) && cur < kNode) { // 8-wide compressed node: one 128-byte line, 96 bytes read
 					const float4 *n = nodes8 + (size_t)cur * 8u;
 					const float4 h = n[0], qa = n[1], qb = n[2], qc = n[3], ra = n[4], rb = n[5];
 					const uint32_t meta = __float_as_uint(h.w);
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 						cur = pick(key[0]);
 					}
 				}
-				if (WIDTH == 2 && cur < kNode) { // dual-AABB node: glsl:243-318
+				if ((WIDTH == 2 || (TL && !in_blas)) && cur < kNode) { // dual-AABB node: glsl:243-318 (TL: every TLAS node)
 					const float4 *n = nodes + (size_t)cur * 4u;
 					const float4 a = n[0], b = n[1], c = n[2], d = n[3];
 					const float l0x = fma_(a.x, ix, nrx), l1x = fma_(b.x, ix, nrx);
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 					push(kInstanceReturn);
 					in_blas = true; cur_inst = slot0;
 					id_base = __float_as_uint(meta.z);
-					cur = __float_as_uint(meta.y);
+					cur = WIDTH == 8 ? __float_as_uint(row[6].z) : __float_as_uint(meta.y); // the BLAS root in the layout walked
 				} else cur = pop();
 			} else if (cur >= kLeafBit) {
 				// the ray the triangles are tested with: the world ray, or (TL) the mesh-space ray of the instance

@@ -153,6 +153,7 @@ constexpr uint32_t kInstanceReturn = 0x7FFFFFFEu; // stack marker: back from a B
 constexpr uint32_t MRT_KERNEL_TWO_LEVEL = 100u;    // internal kernel ids (TraceParams.kernel): one lane per ray,
 constexpr uint32_t MRT_KERNEL_TWO_LEVEL_PACKET = 101u; // one wave per 64-ray packet (coherent batches)
 constexpr uint32_t MRT_KERNEL_TWO_LEVEL_PERSISTENT = 102u; // resident waves, node / leaf phases (large incoherent batches)
+constexpr uint32_t MRT_KERNEL_TWO_LEVEL_PERSISTENT8 = 103u; // the same with 8-wide compressed BLAS nodes
 struct alignas(16) DevInstance {
 	float inv[12];      // world -> object, rows {m00 m01 m02 tx}: o' = M o + t, d' = M d (no renormalisation: t stays world-parameterised)
 	float basis[9];     // object -> world 3x3 (normals: normalize(basis n))
@@ -161,11 +162,12 @@ struct alignas(16) DevInstance {
 	uint32_t layers;    // the mesh's layer mask
 	uint32_t flags;     // 1 = last instance of its TLAS leaf
 	uint32_t index;     // registration index
-	uint32_t pad[6];
+	uint32_t root8;     // BLAS root in the 8-wide layout (scenes that have it)
+	uint32_t pad[5];
 };
 static_assert(sizeof(DevInstance) == 128, "DevInstance must be 128 bytes");
 
-struct TwoLevelBlas { uint32_t first_tri, n_tris, root, depth; float lo[3], hi[3]; };
+struct TwoLevelBlas { uint32_t first_tri, n_tris, root, depth; float lo[3], hi[3]; uint32_t root8, stack8; };
 struct TwoLevelHost {
 	DevNode *nodes = nullptr; uint32_t n_nodes = 0, tlas_cap = 0, n_tlas_nodes = 0;
 	TriHot *hot = nullptr; TriCold *cold = nullptr; uint32_t n_tris = 0;   // all BLAS triangles, mesh-space
@@ -173,6 +175,10 @@ struct TwoLevelHost {
 	TwoLevelBlas *blas = nullptr; uint32_t n_blas = 0;
 	uint32_t *inst_blas = nullptr;   // per registered instance: its BLAS
 	uint32_t depth = 0;              // stack entries one ray can need
+	// optional 8-wide compressed layout of every BLAS (the persistent kernel's walk for incoherent rays)
+	Dev8Node *nodes8 = nullptr; uint32_t n_nodes8 = 0; float *leaf_box = nullptr;
+	bool wide8 = false;              // every BLAS has it (set by the builder of the BLASes)
+	uint32_t depth8 = 0;             // stack entries with 8-wide BLAS walks
 	uint64_t flat_tris = 0;          // triangles of the flattened scene (sum over instances)
 };
 void free_two_level(TwoLevelHost *h);
