@@ -171,6 +171,31 @@ __device__ __forceinline__ void finish_ray(const TraceParams &p, uint64_t ray_id
 	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
 }
 
+// The same for a two-level scene (SceneTLAS::cast_ray, src/accel/scene_tlas.h:217-244): prim_id = the flat
+// id (instance id base + mesh-local index, already in best_id), hit_layers = the instance's mask, normal =
+// normalize(basis * mesh-space normal); DevInstance row = 8 float4: basis at words 12..20, mask at word 23.
+__device__ __forceinline__ void finish_two_level_ray(const TraceParams &p, uint64_t ray_idx, const RayRegs &r,
+		float best_t, float best_u, float best_v, uint32_t best_slot, uint32_t best_id, uint32_t best_inst)
+{
+	int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
+	if (best_slot != 0xFFFFFFFFu) {
+		prim = (int32_t)best_id;
+		if (p.out_fmt != OUT_BOOL8) {
+			const float4 *row = reinterpret_cast<const float4 *>(p.instances) + (size_t)best_inst * 8u;
+			const float4 b0 = row[3], b1 = row[4], b2 = row[5];
+			const float4 no = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
+			nx = fma_(b0.x, no.x, fma_(b0.y, no.y, b0.z * no.z));
+			ny = fma_(b0.w, no.x, fma_(b1.x, no.y, b1.y * no.z));
+			nz = fma_(b1.z, no.x, fma_(b1.w, no.y, b2.x * no.z));
+			const float l2 = fma_(nx, nx, fma_(ny, ny, nz * nz));
+			if (l2 == 0.0f) { nx = ny = nz = 0.0f; }
+			else { const float l = __builtin_sqrtf(l2); nx /= l; ny /= l; nz /= l; }
+			layers = __float_as_uint(b2.w);
+		}
+	}
+	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
+}
+
 // ---- the traversal kernel: one lane = one ray -------------------------------------
 // LDS: per-lane stack, entry d of lane l at dword d*64 + l of the wave's region
 // (conflict-free: the 64 lanes of a push/pop hit 64 consecutive dwords).

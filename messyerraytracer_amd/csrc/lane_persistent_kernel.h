@@ -113,25 +113,14 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 			// (not finish_ray(): its output-format branch around these loads measured 11 % slower here,
 			// 8.6 against 7.7 ms at C4; the lookups are unconditional in this kernel)
 			int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
-			if (TL && best_slot != 0xFFFFFFFFu) { // flat id, the instance's mask, normalize(basis * mesh-space normal)
-				prim = (int32_t)best_id;
-				const float4 *row = inst + (size_t)best_inst * 8u;
-				const float4 b0 = row[3], b1 = row[4], b2 = row[5];
-				const float4 no = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
-				nx = fma_(b0.x, no.x, fma_(b0.y, no.y, b0.z * no.z));
-				ny = fma_(b0.w, no.x, fma_(b1.x, no.y, b1.y * no.z));
-				nz = fma_(b1.z, no.x, fma_(b1.w, no.y, b2.x * no.z));
-				const float l2 = fma_(nx, nx, fma_(ny, ny, nz * nz));
-				if (l2 == 0.0f) { nx = ny = nz = 0.0f; }
-				else { const float l = __builtin_sqrtf(l2); nx /= l; ny /= l; nz /= l; }
-				layers = __float_as_uint(b2.w);
-			} else if (best_slot != 0xFFFFFFFFu) {
+			if (TL) finish_two_level_ray(p, ray_idx, r, best_t, best_u, best_v, best_slot, best_id, best_inst);
+			else if (best_slot != 0xFFFFFFFFu) {
 				prim = (int32_t)p.tri_hot[best_slot].id;
 				layers = p.tri_hot[best_slot].layers;
 				const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
 				nx = nn.x; ny = nn.y; nz = nn.z;
 			}
-			store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
+			if (!TL) store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
 			has_ray = false;
 		}
 		const unsigned long long idle_mask = __ballot(idle);

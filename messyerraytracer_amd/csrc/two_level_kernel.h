@@ -130,23 +130,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_two_level_kernel(const TracePara
 		}
 	}
 
-	int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
-	if (best_slot != 0xFFFFFFFFu) {
-		prim = (int32_t)best_id;
-		if (p.out_fmt != OUT_BOOL8) {
-			const float4 *row = reinterpret_cast<const float4 *>(p.instances) + (size_t)best_inst * 8u;
-			const float4 b0 = row[3], b1 = row[4], b2 = row[5]; // basis[0..3], basis[4..7], {basis[8], root, id_base, layers}
-			const float4 no = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
-			nx = fma_(b0.x, no.x, fma_(b0.y, no.y, b0.z * no.z));
-			ny = fma_(b0.w, no.x, fma_(b1.x, no.y, b1.y * no.z));
-			nz = fma_(b1.z, no.x, fma_(b1.w, no.y, b2.x * no.z));
-			const float l2 = fma_(nx, nx, fma_(ny, ny, nz * nz));
-			if (l2 == 0.0f) { nx = ny = nz = 0.0f; }
-			else { const float l = __builtin_sqrtf(l2); nx /= l; ny /= l; nz /= l; }
-			layers = __float_as_uint(b2.w);
-		}
-	}
-	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
+	finish_two_level_ray(p, ray_idx, r, best_t, best_u, best_v, best_slot, best_id, best_inst);
 }
 
 // ---- the same walk for coherent batches: one wave = one packet of 64 rays --------------------------
@@ -264,21 +248,5 @@ __global__ __launch_bounds__(MRT_WG) void trace_two_level_packet_kernel(const Tr
 		own = ((own_bits >> sp) & 1ull) != 0ull;
 	}
 
-	int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
-	if (best_slot != 0xFFFFFFFFu) {
-		prim = (int32_t)best_id;
-		if (p.out_fmt != OUT_BOOL8) {
-			const float4 *row = inst + (size_t)best_inst * 8u;
-			const float4 b0 = row[3], b1 = row[4], b2 = row[5];
-			const float4 no = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
-			nx = fma_(b0.x, no.x, fma_(b0.y, no.y, b0.z * no.z));
-			ny = fma_(b0.w, no.x, fma_(b1.x, no.y, b1.y * no.z));
-			nz = fma_(b1.z, no.x, fma_(b1.w, no.y, b2.x * no.z));
-			const float l2 = fma_(nx, nx, fma_(ny, ny, nz * nz));
-			if (l2 == 0.0f) { nx = ny = nz = 0.0f; }
-			else { const float l = __builtin_sqrtf(l2); nx /= l; ny /= l; nz /= l; }
-			layers = __float_as_uint(b2.w);
-		}
-	}
-	store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
+	finish_two_level_ray(p, ray_idx, r, best_t, best_u, best_v, best_slot, best_id, best_inst);
 }
