@@ -185,6 +185,11 @@ def test_blases_built_on_the_device(built):
     with pytest.raises(capi.MrtError) as e:
         c.upload_two_level_scene(one_local, one, blas_on_device=True)
     assert e.value.status == capi.ERR_UNSUPPORTED
+    c.upload_two_level_scene(one_local, one)                      # ... the host builder wraps the root leaf
+    rays = np.concatenate([po.grid_rays((0, 0, -12), (0, 0, 1), 64, 64, 50.0), synth.incoherent_rays(70000, 4)])
+    want = po.OracleTwoLevelScene(one_local, one).trace(rays)
+    for flags in (capi.FLAG_COHERENT, 0):
+        parity.assert_exact(c.cast(rays, flags=flags), want, f"one-triangle mesh flags={flags}")
     c.close(); h.close()
 
 
