@@ -38,6 +38,11 @@ VARIANTS = {
     "asm_tile8x8": (dict(kernel=capi.KERNEL_PACKET_ASM), "tiled"),
     "asm_linear": (dict(kernel=capi.KERNEL_PACKET_ASM), "cast"),
     "asm_fused": (dict(kernel=capi.KERNEL_PACKET_ASM), "fused"),
+    "asm_fused_zorder": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_order=2), "fused"),
+    "asm_linear_zorder": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_order=2), "cast"),
+    "asm_fused_zorder_swz": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_order=2, xcd_swizzle=1), "fused"),
+    "asm_fused_swz": (dict(kernel=capi.KERNEL_PACKET_ASM, xcd_swizzle=1), "fused"),
+    "asm_fused_16x4": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_w_log2=4), "fused"),
     "auto_cast": (dict(), "cast"),
     "auto_tiled": (dict(), "tiled"),
     "persist2_linear": (dict(kernel=capi.KERNEL_LANE_PERSISTENT), "cast"),
