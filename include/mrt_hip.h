@@ -284,7 +284,8 @@ typedef struct mrt_instance {
  * (device).  verts9: mesh-space vertices, 9 floats per triangle, host array or device array
  * (MRT_BUILD_TRIS_ON_DEVICE); instances: host array.  The reference flattens on the host every time
  * an instance moves and rebuilds; with a 288 GB device, flatten + rebuild per frame (a millisecond
- * per million triangles + mrt_build_scene_device) is the instancing path here. */
+ * per million triangles + mrt_build_scene_device) is one instancing path here; the two-level scene
+ * below (mrt_upload_two_level_scene) is the other. */
 int mrt_flatten_instances(mrt_ctx *ctx, const float *verts9, uint32_t n_mesh_tris,
 		const mrt_instance *instances, uint32_t n_instances, uint32_t flags, mrt_tri64 *d_out);
 /* mrt_flatten_instances into a scratch buffer + mrt_build_scene_device over it. */
