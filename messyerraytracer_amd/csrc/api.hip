@@ -141,7 +141,7 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 {
 	std::memset(&p, 0, sizeof(p));
 	p.nodes = ctx->d_nodes; p.nodes4 = ctx->d_nodes4; p.nodes8 = ctx->d_nodes8; p.leaf_box = ctx->d_leaf_box; p.instances = ctx->d_instances; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold;
-	p.stack_depth = ctx->stack_depth; p.n_tris = ctx->n_tris;
+	p.stack_depth = ctx->stack_depth; p.n_tris = ctx->n_tris; p.n_nodes = ctx->n_nodes;
 	if (ctx->opts.stack_override >= ctx->depth && ctx->opts.stack_override <= 64) p.stack_depth = ctx->opts.stack_override;
 	p.counters = ctx->d_counters;
 	p.xcd_swizzle = ctx->opts.xcd_swizzle ? 1 : 0;

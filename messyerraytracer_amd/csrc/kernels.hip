@@ -568,7 +568,8 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		else hipLaunchKernelGGL((trace_two_level_kernel<false>), grid, wg, lds2, stream, p);
 		return hipGetLastError();
 	}
-	if (p.kernel == MRT_KERNEL_PACKET_ASM && !count) { // counting builds use the C++ packet kernel
+	// counting builds use the C++ packet kernel, and so do scenes whose node offsets pass the asm loop's 32 bits
+	if (p.kernel == MRT_KERNEL_PACKET_ASM && !count && p.n_nodes < kAsmNodeLimit) {
 		if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true>), grid, wg, 0, stream, p);
 		else hipLaunchKernelGGL((trace_packet_asm_kernel<false>), grid, wg, 0, stream, p);
 		return hipGetLastError();

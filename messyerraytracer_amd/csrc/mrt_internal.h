@@ -112,6 +112,7 @@ struct TraceParams {
 	uint32_t stack_depth;      // LDS stack entries per lane
 	uint32_t xcd_swizzle;      // 1: remap blockIdx so each XCD owns a contiguous band
 	uint32_t n_tris;           // rows in tri_hot / tri_cold (token validation)
+	uint32_t n_nodes;          // rows in nodes (the hand-written node loop addresses them with a 32-bit byte offset)
 	mrt_camera cam;
 };
 
@@ -149,6 +150,7 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 // One node array: TLAS nodes at [0, tlas_cap) (rebuilt in place when instances move), the BLAS
 // of every distinct mesh behind them, node and leaf refs already global.  A TLAS leaf ref is the
 // first slot of a run of DevInstance rows (leaf order; the last row of a leaf has flags & 1).
+constexpr uint32_t kAsmNodeLimit = 1u << 26;     // packet_asm_kernel.h: node index * 64 must fit 32 bits
 constexpr uint32_t kInstanceReturn = 0x7FFFFFFEu; // stack marker: back from a BLAS to the TLAS walk
 constexpr uint32_t MRT_KERNEL_TWO_LEVEL = 100u;    // internal kernel ids (TraceParams.kernel): one lane per ray,
 constexpr uint32_t MRT_KERNEL_TWO_LEVEL_PACKET = 101u; // one wave per 64-ray packet (coherent batches)

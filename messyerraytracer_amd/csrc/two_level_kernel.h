@@ -227,7 +227,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_two_level_packet_kernel(const Tr
 						sz = __ballot(!dead && safe_inv(ro.dz) < 0.0f);
 				const bool uniform = (sx == 0ull || sx == alive) && (sy == 0ull || sy == alive) && (sz == 0ull || sz == alive);
 				const int oct = uniform ? ((sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0)) : 8;
-				if (oct == 8) {
+				if (oct == 8 || p.n_nodes >= kAsmNodeLimit) { // mixed octants, or node offsets beyond the asm loop's 32 bits
 					uint32_t nn = 0, nt = 0, nd = 0;
 					packet_traverse<8, ANY_HIT, false>(p, ro, bstack, best_t, best_u, best_v, best_slot, nn, nt, nd, root, id_base, &best_id, dead);
 				} else {
