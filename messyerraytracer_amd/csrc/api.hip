@@ -594,7 +594,6 @@ static int flatten_instances(mrt_ctx *ctx, const float *verts9, uint32_t n_mesh_
 		uint32_t n_instances, uint32_t flags, mrt_tri64 *d_out_or_null, mrt_tri64 **d_out_alloc, uint32_t *total)
 {
 	if (!verts9 || !instances || n_instances == 0) return fail(ctx, MRT_ERR_INVALID, "flatten_instances: no instances");
-	if (n_instances > 65535u) return fail(ctx, MRT_ERR_UNSUPPORTED, "flatten_instances: at most 65535 instances per call");
 	std::vector<uint32_t> first(n_instances);
 	uint64_t sum = 0; uint32_t max_tris = 0;
 	for (uint32_t i = 0; i < n_instances; i++) {

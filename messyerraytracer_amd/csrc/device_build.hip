@@ -460,8 +460,11 @@ hipError_t launch_flatten_instances(const float *d_verts9, const mrt_instance *d
 		uint32_t n_instances, uint32_t max_tris_per_instance, mrt_tri64 *d_out, void *stream)
 {
 	if (n_instances == 0 || max_tris_per_instance == 0) return hipSuccess;
-	hipLaunchKernelGGL(flatten_instances_kernel, dim3((max_tris_per_instance + LBVH_WG - 1) / LBVH_WG, n_instances), dim3(LBVH_WG), 0,
-			(hipStream_t)stream, d_verts9, d_instances, d_first_out, d_out);
+	for (uint32_t first = 0; first < n_instances; first += 65535u) { // grid.y is limited to 65535
+		const uint32_t n = n_instances - first < 65535u ? n_instances - first : 65535u;
+		hipLaunchKernelGGL(flatten_instances_kernel, dim3((max_tris_per_instance + LBVH_WG - 1) / LBVH_WG, n), dim3(LBVH_WG), 0,
+				(hipStream_t)stream, d_verts9, d_instances + first, d_first_out + first, d_out);
+	}
 	return hipGetLastError();
 }
 

@@ -210,3 +210,28 @@ def test_a_tree_deeper_than_the_stack_is_refused_not_walked(built):
     rays["t_min"], rays["t_max"] = 0.001, T.FLT_MAX
     parity.assert_exact(c.cast(rays, flags=capi.FLAG_COHERENT), osc.trace(rays), "host tree after a refused device build")
     c.close()
+
+
+def test_more_instances_than_one_launch_takes(built):
+    """70 000 placements of a two-triangle mesh (a launch's grid.y stops at 65 535): the device flatten still
+    equals the oracle's, and the scene built from it gives the oracle's hits."""
+    local = synth.soup(2, 0.3, 5)
+    n = 70000
+    rng = np.random.default_rng(9)
+    inst = np.zeros(n, dtype=T.INSTANCE)
+    inst["first_tri"], inst["n_tris"], inst["layers"] = 0, 2, 0xFFFFFFFF
+    inst["basis"] = np.eye(3, dtype=np.float32).ravel() * np.float32(0.2)
+    inst["origin"] = rng.uniform(-5, 5, (n, 3)).astype(np.float32)
+    want = po.flatten_instances(local, inst)
+    c = capi.Context(0)
+    d_out = c.device_alloc(2 * n * 64)
+    c.flatten_instances(local, inst, d_out)
+    got = np.zeros(2 * n, dtype=T.TRI64)
+    c.d2h(got, d_out)
+    assert got.tobytes() == want.tobytes()
+    c.device_free(d_out)
+    c.build_instanced_scene_device(local, inst)
+    world = synth.flatten_instances(local, inst)
+    rays = synth.incoherent_rays(20000, 2)
+    parity.assert_exact(c.cast(rays), po.OracleScene(world).trace(rays), "70 000 instances")
+    c.close()
