@@ -7,8 +7,10 @@ local, inst = synth.multi_mesh_instances(cfg["n_meshes"], cfg["tris_per_mesh"], 
 n = 1 << 22
 rays = synth.incoherent_rays(n, 7)
 out = {}
+opts = dict(leaf_wait=int(os.environ.get("MRT_LEAF_WAIT", "0")), refill=int(os.environ.get("MRT_REFILL", "0")),
+            stack_override=int(os.environ.get("MRT_LDS_DEPTH", "0")))
 for name in ("two_level", "flat"):
-    c = capi.Context(0)
+    c = capi.Context(0, **opts)
     if name == "two_level":
         c.upload_two_level_scene(local, inst, blas_on_device=True)
     else:
@@ -23,4 +25,5 @@ for name in ("two_level", "flat"):
             s = c.stats(); ms.append(s["last_trace_ms"] + s["last_sort_ms"])
         out[f"{name}_{label}_ms"] = float(np.median(ms[1:])); out[f"{name}_{label}_mrays"] = n / np.median(ms[1:]) / 1e3
     c.close()
+out['opts'] = opts
 print(json.dumps(out))
