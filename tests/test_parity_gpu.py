@@ -768,3 +768,31 @@ def test_non_finite_rays_do_not_disturb_their_neighbours(built, kernel):
         b = c.cast(rays, mode=capi.MODE_ANY_HIT, flags=flags | capi.FLAG_BOOL_OUT)
         assert np.array_equal(b.astype(bool)[good], want["prim_id"][good] >= 0)
     c.close()
+
+
+@pytest.mark.parametrize("tile_order", [1, 2])
+@pytest.mark.parametrize("w,h", [(1024, 512), (1000, 520), (128, 128)])
+def test_tile_order_never_changes_a_result(built, tile_order, w, h):
+    """Row-major tiles or Z-order inside 16x16-tile super-tiles (the default for scenes beyond the Infinity
+    Cache): the same records from every grid entry point, also when the grid does not divide into super-tiles
+    (the mapping then falls back to row-major)."""
+    v = synth.soup(20000, 0.25, 21)
+    scene, osc = capi.Scene(v), po.OracleScene(v)
+    cam = capi.camera_look((0, 0, -12), (0, 0, 1), w, h, 50.0)
+    rays = po.grid_rays((0, 0, -12), (0, 0, 1), w, h, 50.0)
+    want = osc.trace(rays)
+    for kernel in (capi.KERNEL_AUTO, capi.KERNEL_LANE):
+        c = capi.Context(0, kernel=kernel, tile_order=tile_order)
+        scene.upload(c)
+        parity.assert_exact(c.cast_grid(cam, w, h), want, f"cast_grid order={tile_order} kernel={kernel}")
+        parity.assert_exact(c.cast(rays, flags=capi.FLAG_COHERENT), want, f"cast order={tile_order} kernel={kernel}")
+        d_rays, d_hits = c.device_alloc(w * h * 32), c.device_alloc(w * h * 32)
+        c.h2d(d_rays, rays)
+        c.cast_tiled(d_rays, d_hits, w, h)
+        got = np.zeros(w * h, dtype=T.HIT32)
+        c.d2h(got, d_hits)
+        parity.assert_exact(got, want, f"cast_tiled order={tile_order} kernel={kernel}")
+        part = c.cast_grid(cam, w, h, y0=h // 4, y1=h // 2)              # a row block of the grid (multi-GPU sharding)
+        parity.assert_exact(part, want[(h // 4) * w:(h // 2) * w], f"row block order={tile_order} kernel={kernel}")
+        c.device_free(d_rays); c.device_free(d_hits)
+        c.close()
