@@ -796,3 +796,28 @@ def test_tile_order_never_changes_a_result(built, tile_order, w, h):
         parity.assert_exact(part, want[(h // 4) * w:(h // 2) * w], f"row block order={tile_order} kernel={kernel}")
         c.device_free(d_rays); c.device_free(d_hits)
         c.close()
+
+
+@pytest.mark.parametrize("opts", [dict(xcd_swizzle=1), dict(grid_tile=1), dict(sort_key=1), dict(sort_threshold=100000),
+                                  dict(sort_threshold=1), dict(tile_w_log2=2), dict(tile_w_log2=4), dict(xcd_swizzle=1, kernel=capi.KERNEL_LANE),
+                                  dict(xcd_swizzle=1, tile_order=2, tile_w_log2=4)])
+def test_tuning_options_never_change_a_result(built, opts):
+    """Every knob of mrt_options moves work around (lane mapping, workgroup order, sort key, sort threshold);
+    none may move a result: grids and incoherent batches against the oracle under each of them."""
+    v = synth.soup(15000, 0.3, 8)
+    scene, osc = capi.Scene(v), po.OracleScene(v)
+    c = capi.Context(0, **opts)
+    scene.upload(c)
+    w, h = 512, 256
+    cam = capi.camera_look((0, 0, -12), (0, 0, 1), w, h, 50.0)
+    grid = po.grid_rays((0, 0, -12), (0, 0, 1), w, h, 50.0)
+    want = osc.trace(grid)
+    parity.assert_exact(c.cast_grid(cam, w, h), want, f"cast_grid {opts}")
+    parity.assert_exact(c.cast(grid, flags=capi.FLAG_COHERENT), want, f"cast coherent {opts}")
+    inc = synth.incoherent_rays(70000, 12)
+    want = osc.trace(inc)
+    parity.assert_exact(c.cast(inc), want, f"cast incoherent {opts}")
+    parity.assert_exact(c.cast(inc[:300]), want[:300], f"cast small {opts}")
+    b = c.cast(inc, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT)
+    assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
+    c.close()
