@@ -226,3 +226,35 @@ def test_c5_full_grid_two_level_against_flattened(built):
     assert flips <= n // 2000 and diffs <= n // 500
     assert loose <= hit.sum() // 10000
     assert (err <= 2e-4 * scale).all()
+
+
+def test_non_finite_rays_in_a_two_level_scene(built):
+    """NaN / infinite / zero-length rays among valid ones (the reference asserts ray validity in debug builds only):
+    every form of the walk terminates, leaves the valid rays' answers alone and gives the oracle's answer for the rest."""
+    local, inst = _scene(6, 2000, 0.3, 13)
+    osc = po.OracleTwoLevelScene(local, inst)
+    rays = np.tile(po.grid_rays((0, 0, -12), (0, 0, 1), 96, 96, 50.0), 8)[:70000].copy()
+    rng = np.random.default_rng(3)
+    bad = rng.choice(rays.shape[0], 3000, replace=False)
+    vals = np.float32([np.nan, np.inf, -np.inf, 0.0, -0.0, 3.0e38, -3.0e38, 1e-30])
+    for k, i in enumerate(bad):
+        what = k % 4
+        if what == 0:
+            rays["direction"][i] = vals[rng.integers(0, 8, 3)]
+        elif what == 1:
+            rays["origin"][i] = vals[rng.integers(0, 8, 3)]
+        elif what == 2:
+            rays["direction"][i] = 0.0
+        else:
+            rays["t_min"][i], rays["t_max"][i] = vals[rng.integers(0, 8)], vals[rng.integers(0, 8)]
+    good = np.ones(rays.shape[0], dtype=bool)
+    good[bad] = False
+    want = osc.trace(rays)
+    for kernel in (capi.KERNEL_AUTO, capi.KERNEL_LANE):
+        c = capi.Context(0, kernel=kernel)
+        c.upload_two_level_scene(local, inst)
+        for flags in (capi.FLAG_COHERENT, 0):
+            got = c.cast(rays, flags=flags)
+            parity.assert_exact(got[good], want[good], f"valid rays, kernel={kernel} flags={flags}")
+            assert np.array_equal(got["prim_id"][bad], want["prim_id"][bad]), f"non-finite rays, kernel={kernel} flags={flags}"
+        c.close()
