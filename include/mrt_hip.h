@@ -196,7 +196,7 @@ typedef struct mrt_options {
 	                             round-robin placement, which balances cheap and expensive image regions) */
 	uint32_t stack_override;  /* LDS stack entries per lane (lane kernel), >= what the BVH needs    */
 	uint32_t tile_order;      /* 0: by scene size (Z-order once it exceeds the 256 MB Infinity Cache), 1: tiles in
-	                             row-major order, 2: Z-order inside 16x16-tile super-tiles */
+	                             row-major order, 2: Z-order inside 16x16-tile super-tiles, 3: inside 32x32-tile ones */
 	uint32_t sort_key;        /* 0: origin cell + direction Morton key (default), 1: the reference's
 	                             direction-only key (ray_sort.h:64-76); the order never changes results */
 	uint32_t refill;          /* persistent lane kernel: refill a wave when this many lanes are idle (default 16) */

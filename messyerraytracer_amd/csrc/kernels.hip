@@ -77,6 +77,14 @@ __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t 
 			my = (my | (my >> 1)) & 0x33u; my = (my | (my >> 2)) & 0x0Fu;
 			const uint32_t stx = st % (tiles_x >> 4), sty = st / (tiles_x >> 4);
 			tx = (stx << 4) + mx; ty = (sty << 4) + my;
+		} else if (p.tile_order == 2u && (tiles_x & 31u) == 0u && (tiles_y & 31u) == 0u) {
+			// the same with 32x32-tile super-tiles
+			const uint32_t st = (uint32_t)(tile >> 10), in = (uint32_t)tile & 1023u;
+			uint32_t mx = in & 0x155u, my = (in >> 1) & 0x155u; // de-interleave 5+5 bits
+			mx = (mx | (mx >> 1)) & 0x133u; mx = (mx | (mx >> 2)) & 0x10Fu; mx = (mx | (mx >> 4)) & 0x1Fu;
+			my = (my | (my >> 1)) & 0x133u; my = (my | (my >> 2)) & 0x10Fu; my = (my | (my >> 4)) & 0x1Fu;
+			const uint32_t stx = st % (tiles_x >> 5), sty = st / (tiles_x >> 5);
+			tx = (stx << 5) + mx; ty = (sty << 5) + my;
 		} else { tx = (uint32_t)(tile % tiles_x); ty = (uint32_t)(tile / tiles_x); }
 		px = (tx << k) + (l & ((1u << k) - 1u));
 		py = (ty << (6u - k)) + (l >> k);

@@ -770,7 +770,7 @@ def test_non_finite_rays_do_not_disturb_their_neighbours(built, kernel):
     c.close()
 
 
-@pytest.mark.parametrize("tile_order", [1, 2])
+@pytest.mark.parametrize("tile_order", [1, 2, 3])
 @pytest.mark.parametrize("w,h", [(1024, 512), (1000, 520), (128, 128)])
 def test_tile_order_never_changes_a_result(built, tile_order, w, h):
     """Row-major tiles or Z-order inside 16x16-tile super-tiles (the default for scenes beyond the Infinity

@@ -40,6 +40,8 @@ VARIANTS = {
     "asm_fused": (dict(kernel=capi.KERNEL_PACKET_ASM), "fused"),
     "asm_fused_zorder": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_order=2), "fused"),
     "asm_linear_zorder": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_order=2), "cast"),
+    "asm_fused_zorder32": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_order=3), "fused"),
+    "asm_fused_rowmajor": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_order=1), "fused"),
     "asm_fused_zorder_swz": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_order=2, xcd_swizzle=1), "fused"),
     "asm_fused_swz": (dict(kernel=capi.KERNEL_PACKET_ASM, xcd_swizzle=1), "fused"),
     "asm_fused_16x4": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_w_log2=4), "fused"),
