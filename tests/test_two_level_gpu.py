@@ -258,3 +258,26 @@ def test_non_finite_rays_in_a_two_level_scene(built):
             parity.assert_exact(got[good], want[good], f"valid rays, kernel={kernel} flags={flags}")
             assert np.array_equal(got["prim_id"][bad], want["prim_id"][bad]), f"non-finite rays, kernel={kernel} flags={flags}"
         c.close()
+
+
+def test_c5_two_level_kernel_forms_agree_at_full_size(built):
+    """Config C5 as a two-level scene at full size: the packet form and the one-lane-per-ray form give the same 2^26
+    records byte for byte, and so do the persistent form (8-wide BLASes) and the plain lane kernel on 2^22
+    incoherent rays -- the oracle pins the lane form on small scenes, this pins the others to it at scale."""
+    cfg = synth.CONFIGS["C5"]
+    local, inst = synth.multi_mesh_instances(cfg["n_meshes"], cfg["tris_per_mesh"], cfg["s"], cfg["seed"])
+    w, h = cfg["grid"]
+    cam = capi.camera_look(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
+    inc = synth.incoherent_rays(1 << 22, 7)
+    out = {}
+    for kernel in (capi.KERNEL_AUTO, capi.KERNEL_LANE):
+        c = capi.Context(0, kernel=kernel)
+        c.upload_two_level_scene(local, inst, blas_on_device=True)
+        grid = c.cast_grid(cam, w, h)
+        out[kernel] = (grid.tobytes(), c.cast(inc).tobytes(), c.cast(inc, flags=capi.FLAG_COHERENT).tobytes())
+        assert int((grid["prim_id"] >= 0).sum()) > (w * h) // 2
+        del grid
+        c.close()
+    a, b = out[capi.KERNEL_AUTO], out[capi.KERNEL_LANE]
+    assert a[0] == b[0], "packet form != lane form on the 8192^2 grid"
+    assert a[1] == b[1] and a[2] == b[2] and a[1] == a[2], "persistent form != lane form on incoherent rays"
