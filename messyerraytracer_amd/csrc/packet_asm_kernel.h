@@ -17,7 +17,10 @@
 //     sentinel at the bottom, so push/pop cost no scalar instruction and there is no
 //     empty-stack test; an entry also carries the mask of the lanes whose own ray hit the
 //     pushed child's box (needed when it is a leaf: see packet_kernel.h);
-//   * one s_load_dwordx16 with an SGPR offset fetches the 64-byte node.
+//   * one s_load_dwordx16 with an SGPR offset fetches the 64-byte node;
+//   * a pushed inner node is prefetched by a vector load (its own counter, vmcnt: a scalar-load prefetch
+//     would sit in front of the next node's s_waitcnt lgkmcnt(0)); the data is dropped, the line is in the
+//     L2 when the node is popped (1.7 % at C3 and C5).
 // The slab test is the octant-specialised one of packet_kernel.h: 12 v_fma + 8
 // v_max/v_min(3) + 2 v_cmp, bit-identical values.  Leaves (triangle tests) stay in C++.
 // Packets whose rays do not share one octant, and counting builds, use packet_traverse.
@@ -27,7 +30,8 @@
 //   s36..s38 lmin.xyz  s39 left_ref | s40..s42 lmax.xyz  s43 right_ref
 //   s44..s46 rmin.xyz  s47 -        | s48..s50 rmax.xyz  s51 -
 // scratch: s52 byte offset, s53 far ref, s[54:55] right-child mask, s[56:57] "left is nearer" flags,
-// s[58:59] mask of the pushed (far) child, s[60:61] mask of the entered child, v40..v51 slab values.
+// s[58:59] mask of the pushed (far) child, s[60:61] mask of the entered child, v40..v51 slab values,
+// v52 the never-read destination of the far-child prefetch.
 //
 // Stack entries are 16 bytes: {ref, -, lane mask (64 bit)}.  The mask holds the lanes whose OWN ray hit the
 // box of the pushed child; it matters only when that child is a leaf (packet_kernel.h: a lane accepts
@@ -81,6 +85,10 @@
 		"ds_write_b32 %[sp], v41\n"                                                                         \
 		"ds_write_b64 %[sp], v[42:43] offset:8\n"                                                           \
 		"v_add_u32 %[sp], 16, %[sp]\n"                                                                      \
+		"s_bitcmp1_b32 s53, 31\n"           /* the pushed child is an inner node: start pulling it towards */ \
+		"s_cbranch_scc1 L_entered_%=\n"     /* the L2 now; it is popped after the near subtree is done     */ \
+		"v_lshlrev_b32 v44, 6, v41\n"                                                                       \
+		"global_load_dword v52, v44, %[base]\n" /* v52 is never read; vmcnt is drained at the exit         */ \
 		"s_branch L_entered_%=\n"                                                                           \
 		"L_onlyl_%=:\n"                                                                                     \
 		"s_mov_b32 %[node], s39\n"                                                                          \
@@ -107,12 +115,13 @@
 		"s_cmp_lt_u32 %[node], 0x7fffffff\n"                                                                \
 		"s_cbranch_scc1 L_node_%=\n"                                                                        \
 		"L_exit_%=:\n"                                                                                      \
+		"s_waitcnt vmcnt(0)\n"              /* no prefetch may land in v52 once the compiler owns it again */ \
 		: [node] "+s"(node), [sp] "+v"(sp)                                                                  \
 		: [base] "s"(base), [dopop] "s"(dopop), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), [nrx] "v"(nrx),   \
 		  [nry] "v"(nry), [nrz] "v"(nrz), [tmin] "v"(tmin), [lim] "v"(lim)                                  \
 		: "vcc", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45",      \
 		  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", \
-		  "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51")
+		  "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52")
 
 // Walks inner nodes until `node` is a leaf reference (>= 0x80000000) or the sentinel
 // (0x7FFFFFFF = the stack ran empty).  dopop = 1: start by popping (after a leaf).
