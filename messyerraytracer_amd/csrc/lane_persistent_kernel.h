@@ -45,11 +45,13 @@ struct PersistParams {
 	                              // otherwise give a wave only a few chunks (the last ones finish unevenly)
 };
 
-#ifdef MRT_PERSIST_WPE // experiment: ask the register allocator for at least this many waves per SIMD
-#define MRT_PERSIST_ATTR __attribute__((amdgpu_waves_per_eu(MRT_PERSIST_WPE, 8)))
-#else
-#define MRT_PERSIST_ATTR
+// Waves per SIMD the register allocator has to leave room for.  The flat forms need 75-92 VGPRs (5-6 waves) by
+// themselves; the two-level forms come to 118-125 (4 waves) and gain 6 % when held to 96 (2^22 incoherent rays
+// on C5: 8.35 -> 7.8 ms).  Asking for 6 costs every form (C4 8-wide: +3 %, two-level: +8 %).
+#ifndef MRT_PERSIST_WPE
+#define MRT_PERSIST_WPE 5
 #endif
+#define MRT_PERSIST_ATTR __attribute__((amdgpu_waves_per_eu(MRT_PERSIST_WPE, 8)))
 
 // byte k of a packed word as a float (v_cvt_f32_ubyteK)
 __device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xFFu); }

@@ -143,8 +143,11 @@ __global__ __launch_bounds__(MRT_WG) void trace_two_level_kernel(const TracePara
 // mesh-space rays of the lanes that take part share one octant, packet_traverse<8> otherwise.  A lane
 // whose world ray missed the instance's box sits that walk out with an empty interval (no box test
 // can pass), so every lane reports exactly what the one-ray walk above reports.
+// Registers: the world ray, the mesh-space ray and the walkers' state come to 83 VGPRs = 5 waves per SIMD, and
+// the dependent scalar node fetches want more waves to hide behind: held to 72 VGPRs (7 waves, no spills) the C5
+// grid goes from 43.0 to 34.1 ms; 64 VGPRs (8 waves) spills 38 registers and is no faster (any-hit: slower).
 template <bool ANY_HIT>
-__global__ __launch_bounds__(MRT_WG) void trace_two_level_packet_kernel(const TraceParams p)
+__global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_waves_per_eu(7, 8))) void trace_two_level_packet_kernel(const TraceParams p)
 {
 	__shared__ __attribute__((aligned(16))) uint32_t blas_stack[MRT_WG / MRT_WAVE][(MRT_PACKET_STACK + 1) * 4]; // 16-byte entries (packet_asm_kernel.h)
 	__shared__ uint32_t tlas_stack[MRT_WG / MRT_WAVE][MRT_PACKET_STACK];
