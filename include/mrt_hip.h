@@ -114,14 +114,28 @@ typedef struct mrt_host_tri80 {
 	uint32_t id, layers;
 } mrt_host_tri80;
 
-/* Camera for the on-device primary-ray grid: the formula of
- * RayTracerDebug::cast_debug_rays, src/godot/raytracer_debug.cpp:572-596.
- * mrt_camera_look() fills basis + half extents on the host exactly as :573-583. */
+/* Camera for the on-device primary-ray grids.  Three generators, chosen by `kind`:
+ *   MRT_CAMERA_DEBUG_GRID   RayTracerDebug::cast_debug_rays, src/godot/raytracer_debug.cpp:572-596
+ *                           (mrt_camera_look fills basis + half extents on the host exactly as :573-583):
+ *                           dir = normalize(fwd + right u + up v), v grows with the row index;
+ *   MRT_CAMERA_PERSPECTIVE  RayCamera::_generate_perspective, src/modules/graphics/ray_camera.h:234-251 --
+ *                           the generator behind every coherent=true query of the renderer
+ *                           (ray_renderer.cpp:521-537): v is FLIPPED (row 0 = top),
+ *                           dir = normalize(basis.xform((u half_w, v half_h, -1)));
+ *   MRT_CAMERA_ORTHOGRAPHIC RayCamera::_generate_orthographic, ray_camera.h:255-273: parallel rays,
+ *                           origin = (origin + up (v half_h)) + right (u half_w), direction = -basis column 2.
+ * For the two RayCamera kinds right / up / fwd hold the columns 0 / 1 / 2 of the camera basis
+ * (fwd = column 2 as it stands: the camera looks along its negative). */
+enum { MRT_CAMERA_DEBUG_GRID = 0, MRT_CAMERA_PERSPECTIVE = 1, MRT_CAMERA_ORTHOGRAPHIC = 2 };
 typedef struct mrt_camera {
 	float origin[3];
 	float fwd[3], right[3], up[3];
 	float half_w, half_h;
 	float t_min, t_max;     /* Ray() defaults: 0.001f, FLT_MAX (ray.h:59) */
+	uint32_t kind;          /* MRT_CAMERA_* */
+	float inv_w, inv_h;     /* RayCamera kinds: 1.0f / width, 1.0f / height (ray_camera.h:56-57) */
+	float jitter_x, jitter_y; /* RayCamera kinds: sub-pixel offset, 0.5 = pixel centre (generate_ray_jittered, :106-122) */
+	uint32_t reserved[3];
 } mrt_camera;
 
 /* RayStats, src/core/stats.h:20-55, plus device timing of the last cast. */
@@ -139,7 +153,13 @@ typedef struct mrt_stats {
 	uint32_t detected_grid_w;    /* count_visits: row width found for the last coherent mrt_cast (0 = none) */
 	uint32_t reserved;           /* count_visits: 1 if the last batch declared coherent was judged incoherent on the device */
 	float last_build_ms;         /* device time of the last mrt_build_scene_device */
-	uint32_t reserved2;
+	uint32_t last_kernel;        /* MRT_KERNEL_* that did the work of the last blocking cast (a batch declared coherent is
+	                                checked on the device: this is the kernel the device chose); 0 after an ASYNC cast */
+	/* count_visits, memory-side view of the walk (what the roofline of bench.py prices): */
+	uint64_t wave_node_fetches;  /* node fetches issued: one per wave step in the packet kernels (the node is fetched once
+	                                for 64 rays), one per lane step (= one divergent cache line) in the lane kernels */
+	uint64_t wave_tri_fetches;   /* 48-byte triangle rows fetched, counted the same way */
+	uint64_t leaf_box_checks;    /* 8-wide kernel: exact 32-byte leaf boxes read for candidate hits */
 } mrt_stats;
 
 /* mode: RayQuery::Mode, src/api/ray_query.h:54-57 / RAY_MODE spec constant,
@@ -173,16 +193,22 @@ enum {
 	MRT_KERNEL_AUTO = 0,
 	MRT_KERNEL_LANE = 1,    /* one lane = one ray, per-lane LDS stack, while-while loop         */
 	MRT_KERNEL_PACKET = 2,  /* one wave = one 64-ray packet, per-wave LDS stack, scalar fetches */
-	MRT_KERNEL_PACKET4 = 3, /* retired (a packet walk over the 4-wide collapse): runs MRT_KERNEL_PACKET */
-	MRT_KERNEL_PACKET2 = 4, /* retired (two packets per wave in lockstep): runs MRT_KERNEL_PACKET      */
+	/* 3 and 4 were two packet-walk experiments of round 1 (4-wide nodes, two packets per wave); retired, ids not reused */
 	MRT_KERNEL_PACKET_ASM = 5, /* packet walk with the hand-written gfx950 node loop (default for coherent batches) */
 	MRT_KERNEL_LANE_PERSISTENT = 6, /* lane kernel with resident waves pulling rays from a counter, short LDS
 	                                  stack + HBM spill, node / leaf phases                                */
 	MRT_KERNEL_LANE4_PERSISTENT = 7, /* the same over the 4-wide collapse of the BVH, one 128-byte line per step */
-	MRT_KERNEL_LANE8_PERSISTENT = 8 /* the same over an 8-wide collapse with 8-bit child boxes on a per-node grid
+	MRT_KERNEL_LANE8_PERSISTENT = 8, /* the same over an 8-wide collapse with 8-bit child boxes on a per-node grid
 	                                  (compressed wide BVH, cf. the reference's cwbvh_traverse.comp.glsl), one
 	                                  128-byte line per step (default for large incoherent batches)       */
+	MRT_KERNEL_PACKET_DUAL = 9, /* two 64-ray packets per wave walked in lockstep by one hand-written node loop: twice the
+	                               node fetches in flight at the same occupancy (the packet walk is latency-bound)   */
+	/* reported in mrt_stats.last_kernel only (chosen by the library for two-level scenes, not selectable): */
+	MRT_KERNEL_TWO_LEVEL = 100, MRT_KERNEL_TWO_LEVEL_PACKET = 101, MRT_KERNEL_TWO_LEVEL_PERSISTENT = 102,
+	MRT_KERNEL_TWO_LEVEL_PERSISTENT8 = 103
 };
+/* Name of the __global__ function behind a kernel id ("trace_packet_asm_kernel", ...); "?" for an unknown id. */
+const char *mrt_kernel_name(uint32_t kernel);
 
 typedef struct mrt_options {
 	uint32_t struct_size;     /* = sizeof(mrt_options) */
@@ -202,7 +228,9 @@ typedef struct mrt_options {
 	uint32_t refill;          /* persistent lane kernel: refill a wave when this many lanes are idle (default 16) */
 	uint32_t leaf_wait;       /* persistent lane kernel: leave the node phase when this many lanes stand at a
 	                             leaf (default 8 for the 8-wide walk, else 16; 64 = classic while-while) */
-	uint32_t reserved[4];
+	uint32_t extra_lds;       /* experiments: bytes of dynamic LDS added to every packet-kernel workgroup, which lowers
+	                             the number of resident waves (occupancy sweeps, tools/exp_occupancy.py); <= 60000 */
+	uint32_t reserved[3];
 } mrt_options;
 
 typedef struct mrt_ctx mrt_ctx;
@@ -213,6 +241,9 @@ void mrt_destroy(mrt_ctx *ctx);
 const char *mrt_last_error(const mrt_ctx *ctx);
 const char *mrt_status_string(int status);
 uint32_t mrt_version(void);
+/* sizeof() of the boundary's structs as this library was compiled, for bindings in other languages to check
+ * their own declarations against: 0 mrt_options, 1 mrt_camera, 2 mrt_stats, 3 mrt_instance (0 for anything else). */
+uint32_t mrt_struct_size(uint32_t which);
 /* Launch on this HIP stream (hipStream_t as void*; 0 = the context's own stream). */
 int mrt_set_stream(mrt_ctx *ctx, void *hip_stream);
 int mrt_synchronize(mrt_ctx *ctx);
@@ -331,6 +362,14 @@ int mrt_has_pending(const mrt_ctx *ctx);
 /* ---- primary-ray grids on the device (raytracer_debug.cpp:572-596) ---------- */
 int mrt_camera_look(mrt_camera *cam, const float origin[3], const float forward[3],
 		uint32_t grid_w, uint32_t grid_h, float fov_degrees);
+/* RayCamera::setup + _setup_perspective / _setup_orthographic (ray_camera.h:50-76,208-230) without the
+ * Camera3D: origin and basis (row-major 3x3 = Godot's Basis rows) are the camera transform, width x height
+ * the resolution the grid will be cast at.  Pass the camera to mrt_generate_grid / mrt_cast_grid /
+ * mrt_expand_grid_tokens with the same width and height. */
+int mrt_camera_perspective(mrt_camera *cam, const float origin[3], const float basis[9],
+		uint32_t width, uint32_t height, float fov_degrees);
+int mrt_camera_orthographic(mrt_camera *cam, const float origin[3], const float basis[9],
+		uint32_t width, uint32_t height, float size);
 /* rows [y0,y1) of a grid_w x grid_h grid, row-major from row y0, into d_rays. */
 int mrt_generate_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t grid_h,
 		uint32_t y0, uint32_t y1, mrt_ray32 *d_rays);

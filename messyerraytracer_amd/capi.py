@@ -20,17 +20,18 @@ MODE_NEAREST, MODE_ANY_HIT = 0, 1
 FLAG_COHERENT, FLAG_RAYS_ON_DEVICE, FLAG_HITS_ON_DEVICE, FLAG_HOST_LAYOUT, FLAG_BOOL_OUT, FLAG_FORCE_SORT, FLAG_TOKEN_OUT, FLAG_ASYNC = (1 << i for i in range(8))
 TOKEN_MISS = 0xFFFFFFFF
 BUILD_TRIS_ON_DEVICE, BUILD_SAFE_HANDOFF, BUILD_BLAS_ON_DEVICE = 1, 2, 4
-KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET, KERNEL_PACKET4, KERNEL_PACKET2, KERNEL_PACKET_ASM, KERNEL_LANE_PERSISTENT, \
-    KERNEL_LANE4_PERSISTENT, KERNEL_LANE8_PERSISTENT = range(9)
+KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET = 0, 1, 2   # (3 and 4: retired experiments, ids not reused)
+KERNEL_PACKET_ASM, KERNEL_LANE_PERSISTENT, KERNEL_LANE4_PERSISTENT, KERNEL_LANE8_PERSISTENT, KERNEL_PACKET_DUAL = 5, 6, 7, 8, 9
+KERNEL_TWO_LEVEL, KERNEL_TWO_LEVEL_PACKET, KERNEL_TWO_LEVEL_PERSISTENT, KERNEL_TWO_LEVEL_PERSISTENT8 = 100, 101, 102, 103  # reported only
 
 # every entry point include/mrt_hip.h declares (tests check they are all exported)
 SYMBOLS = [
     "mrt_create", "mrt_destroy", "mrt_last_error", "mrt_status_string", "mrt_version", "mrt_set_stream",
     "mrt_synchronize", "mrt_make_triangles", "mrt_pack_host_triangles", "mrt_bvh2_build", "mrt_bvh2_save", "mrt_bvh2_load", "mrt_upload_scene",
     "mrt_build_scene_device", "mrt_flatten_instances", "mrt_build_instanced_scene_device", "mrt_upload_two_level_scene", "mrt_update_instances", "mrt_is_available", "mrt_scene_info", "mrt_cast", "mrt_submit", "mrt_collect", "mrt_has_pending",
-    "mrt_camera_look", "mrt_generate_grid", "mrt_cast_grid", "mrt_cast_tiled", "mrt_expand_tokens",
+    "mrt_camera_look", "mrt_camera_perspective", "mrt_camera_orthographic", "mrt_generate_grid", "mrt_cast_grid", "mrt_cast_tiled", "mrt_expand_tokens",
     "mrt_expand_grid_tokens", "mrt_morton_keys",
-    "mrt_get_stats", "mrt_device_alloc", "mrt_device_free", "mrt_memcpy_h2d", "mrt_memcpy_d2h",
+    "mrt_kernel_name", "mrt_struct_size", "mrt_get_stats", "mrt_device_alloc", "mrt_device_free", "mrt_memcpy_h2d", "mrt_memcpy_d2h",
 ]
 
 
@@ -45,12 +46,14 @@ class Options(C.Structure):
                 ("sort_threshold", C.c_uint32), ("grid_tile", C.c_uint32), ("tile_w_log2", C.c_uint32),
                 ("xcd_swizzle", C.c_uint32), ("stack_override", C.c_uint32), ("tile_order", C.c_uint32),
                 ("sort_key", C.c_uint32), ("refill", C.c_uint32), ("leaf_wait", C.c_uint32),
-                ("reserved", C.c_uint32 * 4)]
+                ("extra_lds", C.c_uint32), ("reserved", C.c_uint32 * 3)]
 
 
 class Camera(C.Structure):
     _fields_ = [("origin", C.c_float * 3), ("fwd", C.c_float * 3), ("right", C.c_float * 3), ("up", C.c_float * 3),
-                ("half_w", C.c_float), ("half_h", C.c_float), ("t_min", C.c_float), ("t_max", C.c_float)]
+                ("half_w", C.c_float), ("half_h", C.c_float), ("t_min", C.c_float), ("t_max", C.c_float),
+                ("kind", C.c_uint32), ("inv_w", C.c_float), ("inv_h", C.c_float), ("jitter_x", C.c_float), ("jitter_y", C.c_float),
+                ("reserved", C.c_uint32 * 3)]
 
 
 class Stats(C.Structure):
@@ -58,7 +61,8 @@ class Stats(C.Structure):
                 ("hits", C.c_uint64), ("last_trace_ms", C.c_float), ("last_sort_ms", C.c_float),
                 ("last_h2d_ms", C.c_float), ("last_d2h_ms", C.c_float), ("last_kernel_launches", C.c_uint32),
                 ("max_stack_depth", C.c_uint32), ("dead_pops", C.c_uint64), ("detected_grid_w", C.c_uint32), ("reserved", C.c_uint32),
-                ("last_build_ms", C.c_float), ("reserved2", C.c_uint32)]
+                ("last_build_ms", C.c_float), ("last_kernel", C.c_uint32),
+                ("wave_node_fetches", C.c_uint64), ("wave_tri_fetches", C.c_uint64), ("leaf_box_checks", C.c_uint64)]
 
 
 _lib = None
@@ -76,6 +80,10 @@ def load():
     L.mrt_last_error.restype = C.c_char_p
     L.mrt_status_string.restype = C.c_char_p
     L.mrt_version.restype = C.c_uint32
+    L.mrt_struct_size.restype = C.c_uint32
+    L.mrt_struct_size.argtypes = [C.c_uint32]
+    L.mrt_kernel_name.restype = C.c_char_p
+    L.mrt_kernel_name.argtypes = [C.c_uint32]
     L.mrt_create.argtypes = [C.c_int, C.POINTER(Options), C.POINTER(C.c_void_p)]
     L.mrt_destroy.argtypes = [C.c_void_p]
     L.mrt_destroy.restype = None
@@ -100,6 +108,8 @@ def load():
     L.mrt_collect.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
     L.mrt_has_pending.argtypes = [C.c_void_p]
     L.mrt_camera_look.argtypes = [C.POINTER(Camera), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_float]
+    L.mrt_camera_perspective.argtypes = [C.POINTER(Camera), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_float]
+    L.mrt_camera_orthographic.argtypes = [C.POINTER(Camera), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_uint32, C.c_float]
     L.mrt_generate_grid.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p]
     L.mrt_cast_grid.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32,
                                 C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
@@ -179,6 +189,10 @@ def bvh2_load(path: str, n_tris: int):
     return nodes[:used.value].copy(), prim_idx, used.value
 
 
+def kernel_name(kernel_id: int) -> str:
+    return load().mrt_kernel_name(kernel_id).decode()
+
+
 def camera_look(origin, forward, grid_w, grid_h, fov_degrees) -> Camera:
     cam = Camera()
     o = (C.c_float * 3)(*origin)
@@ -189,13 +203,27 @@ def camera_look(origin, forward, grid_w, grid_h, fov_degrees) -> Camera:
     return cam
 
 
+def ray_camera(origin, basis, width, height, param, ortho=False, jitter=(0.5, 0.5)) -> Camera:
+    """RayCamera::setup (ray_camera.h:50-76): basis = 3x3 row-major camera basis; param = vertical fov in degrees
+    (perspective) or Camera3D::size (orthographic); jitter = sub-pixel offset of generate_rays_tile_jittered."""
+    cam = Camera()
+    o = (C.c_float * 3)(*origin)
+    b = (C.c_float * 9)(*np.asarray(basis, dtype=np.float32).reshape(9))
+    fn = load().mrt_camera_orthographic if ortho else load().mrt_camera_perspective
+    rc = fn(C.byref(cam), o, b, width, height, param)
+    if rc:
+        raise MrtError(rc, "mrt_camera_orthographic" if ortho else "mrt_camera_perspective")
+    cam.jitter_x, cam.jitter_y = jitter
+    return cam
+
+
 class Context:
     """mrt_ctx wrapper: one per GPU, externally serialised (SURVEY 8(b) threading)."""
 
     def __init__(self, device: int = 0, kernel: int = KERNEL_AUTO, count_visits: bool = False,
                  sort_threshold: int = 0, grid_tile: int = 0, tile_w_log2: int = 0, xcd_swizzle: int = 0,
                  stack_override: int = 0, tile_order: int = 0, sort_key: int = 0, refill: int = 0,
-                 leaf_wait: int = 0):
+                 leaf_wait: int = 0, extra_lds: int = 0):
         self.L = load()
         opts = Options()
         opts.struct_size = C.sizeof(Options)
@@ -210,6 +238,7 @@ class Context:
         opts.sort_key = sort_key
         opts.refill = refill
         opts.leaf_wait = leaf_wait
+        opts.extra_lds = extra_lds
         self.h = C.c_void_p()
         rc = self.L.mrt_create(device, C.byref(opts), C.byref(self.h))
         if rc:

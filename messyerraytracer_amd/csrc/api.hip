@@ -33,7 +33,7 @@ hipError_t launch_trace_persistent(const TraceParams &p, unsigned long long *nex
 hipError_t launch_origin_dir_keys(const void *rays, uint32_t in_fmt, uint64_t count, const float lo[3], const float hi[3],
 		uint32_t *keys, uint32_t *index, hipStream_t stream);
 hipError_t launch_detect_grid(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t tile_w_log2,
-		unsigned long long *scratch, uint32_t *out, hipStream_t stream);
+		unsigned long long *scratch, uint32_t *out, uint32_t *host_out, hipStream_t stream);
 }
 
 struct DevBuf {
@@ -63,6 +63,10 @@ struct mrt_ctx {
 	DevBuf rays, hits, keys_in, keys_out, idx_in, idx_out, sort_tmp, overflow;
 	int cu_count = 256;
 	unsigned long long *d_counters = nullptr;
+	// what detect_grid_kernel decided, also written to this host-mapped word block {row width, rows, tiles_x, verdict}
+	// so that the host knows after the stream sync which of the two queued kernels did the work (no extra copy)
+	uint32_t *h_auto = nullptr, *d_auto_host = nullptr;
+	uint32_t queued_kernel = 0, queued_alt_kernel = 0; bool queued_detect = false; // what the last enqueue_cast put on the stream
 	// host-array pipeline (cast_host_pipelined): copy streams and per-chunk events, created on first use
 	hipStream_t up_stream = nullptr, dn_stream = nullptr;
 	std::vector<hipEvent_t> pipe_ev;
@@ -152,6 +156,7 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 	const size_t scene_bytes = (size_t)ctx->n_nodes * sizeof(mrt::DevNode) + (size_t)ctx->n_tris * (sizeof(mrt::TriHot) + sizeof(mrt::TriCold));
 	p.tile_order = ctx->opts.tile_order == 2 || (ctx->opts.tile_order == 0 && scene_bytes > (size_t)256 << 20) ? 1u : 0u;
 	if (ctx->opts.tile_order == 3) p.tile_order = 2u; // 32x32-tile super-tiles (C5: 23.3 against 23.5 ms; not the default)
+	p.extra_lds = ctx->opts.extra_lds <= 60000u ? ctx->opts.extra_lds : 60000u;
 	p.kernel = MRT_KERNEL_LANE; // callers pick per batch with pick_kernel()
 }
 
@@ -161,9 +166,7 @@ uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent)
 {
 	// a two-level scene has its own pair of kernels (two_level_kernel.h)
 	if (ctx->two_level) return coherent && ctx->opts.kernel != MRT_KERNEL_LANE ? mrt::MRT_KERNEL_TWO_LEVEL_PACKET : mrt::MRT_KERNEL_TWO_LEVEL;
-	// the 4-wide and the dual packet walks are retired (slower than the plain packet loop, and not
-	// exact for rays that lie in a box face): their ids run the packet kernel
-	if (ctx->opts.kernel == MRT_KERNEL_PACKET4 || ctx->opts.kernel == MRT_KERNEL_PACKET2) return MRT_KERNEL_PACKET;
+	if (ctx->opts.kernel == MRT_KERNEL_PACKET_DUAL) return coherent ? MRT_KERNEL_PACKET_DUAL : MRT_KERNEL_LANE;
 	if (ctx->opts.kernel >= MRT_KERNEL_LANE && ctx->opts.kernel <= MRT_KERNEL_LANE8_PERSISTENT) return ctx->opts.kernel;
 	// PACKET_ASM: same walk with the hand-written node loop (the compiler's loop is scalar-ALU bound)
 	return coherent ? MRT_KERNEL_PACKET_ASM : MRT_KERNEL_LANE;
@@ -212,6 +215,7 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 	if (!persistent || ctx->opts.count_visits) {
 		p.kernel = ctx->two_level ? mrt::MRT_KERNEL_TWO_LEVEL : MRT_KERNEL_LANE;
 		HIP_TRY(ctx, mrt::launch_trace(p, any_hit, ctx->opts.count_visits != 0, ctx->stream));
+		ctx->queued_kernel = p.kernel;
 		return MRT_OK;
 	}
 	const uint32_t lds_depth = ctx->opts.stack_override >= 4 && ctx->opts.stack_override <= 64 ? ctx->opts.stack_override : 16u;
@@ -229,10 +233,11 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 	p.kernel = wide8 ? MRT_KERNEL_LANE8_PERSISTENT : (wide4 ? MRT_KERNEL_LANE4_PERSISTENT : MRT_KERNEL_LANE_PERSISTENT);
 	if (ctx->two_level) p.kernel = wide8 ? mrt::MRT_KERNEL_TWO_LEVEL_PERSISTENT8 : mrt::MRT_KERNEL_TWO_LEVEL_PERSISTENT; // need = stack8 (= depth8) / depth
 	// eight ray counters (one per region of the batch), 128 bytes apart
-	unsigned long long *next_ray = ctx->d_counters + 16 + 1026;
+	unsigned long long *next_ray = ctx->d_counters + mrt::kNextRayOff;
 	HIP_TRY(ctx, hipMemsetAsync(next_ray, 0, 128 * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace_persistent(p, next_ray, ovf, lds_depth, ctx->opts.refill ? ctx->opts.refill : 16u,
 			ctx->opts.leaf_wait ? ctx->opts.leaf_wait : (wide8 ? 8u : 16u), (uint32_t)blocks, any_hit, ctx->stream));
+	ctx->queued_kernel = p.kernel;
 	return MRT_OK;
 }
 
@@ -283,21 +288,25 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 			p.kernel == MRT_KERNEL_LANE8_PERSISTENT;
 	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 4096 && ctx->opts.grid_tile != 1 && !persistent_kind;
 	if (detect) {
-		uint32_t *d_auto = reinterpret_cast<uint32_t *>(ctx->d_counters + 8);
-		HIP_TRY(ctx, mrt::launch_detect_grid(d_rays, p.in_fmt, count, p.tile_w_log2, ctx->d_counters + 16, d_auto, ctx->stream));
+		uint32_t *d_auto = reinterpret_cast<uint32_t *>(ctx->d_counters + mrt::kAutoGridOff);
+		HIP_TRY(ctx, mrt::launch_detect_grid(d_rays, p.in_fmt, count, p.tile_w_log2, ctx->d_counters + mrt::kDetectScratchOff, d_auto, ctx->d_auto_host, ctx->stream));
 		p.lane_map = mrt::MAP_AUTO; p.auto_grid = d_auto;
 	}
-	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));
 	const bool any = mode == MRT_MODE_ANY_HIT;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+	ctx->queued_detect = detect; ctx->queued_alt_kernel = 0;
 	if (detect && ctx->opts.kernel == MRT_KERNEL_AUTO && !ctx->opts.count_visits) {
 		// The caller said "coherent"; the device checks.  Packet launch first, lane launch behind it:
 		// detect_grid_kernel's verdict (d_auto[3]) makes exactly one of them do the work.
 		p.skip_flag = p.auto_grid + 3; p.skip_when = 1u;
 		HIP_TRY(ctx, mrt::launch_trace(p, any, false, ctx->stream));
+		const uint32_t packet_kernel = p.kernel;
 		mrt::TraceParams lp = p;
 		lp.kernel = MRT_KERNEL_LANE; lp.lane_map = mrt::MAP_LINEAR; lp.auto_grid = nullptr; lp.skip_when = 0u;
 		if ((rc = launch_lane(ctx, lp, count, any, count >= 65536))) return rc; // (a two-level scene: its own lane kernels)
+		ctx->queued_alt_kernel = ctx->queued_kernel; // what launch_lane queued: runs if the batch is judged incoherent
+		ctx->queued_kernel = packet_kernel;
 	} else {
 		// large incoherent batches: resident waves that pull rays from a counter (no counting variant)
 		const bool persistent = !ctx->opts.count_visits && p.lane_map == mrt::MAP_LINEAR &&
@@ -305,7 +314,10 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 					(p.kernel == MRT_KERNEL_LANE || p.kernel == mrt::MRT_KERNEL_TWO_LEVEL)));
 		if (persistent_kind || p.kernel == MRT_KERNEL_LANE || p.kernel == mrt::MRT_KERNEL_TWO_LEVEL) {
 			if ((rc = launch_lane(ctx, p, count, any, persistent))) return rc;
-		} else HIP_TRY(ctx, mrt::launch_trace(p, any, ctx->opts.count_visits != 0, ctx->stream));
+		} else {
+			HIP_TRY(ctx, mrt::launch_trace(p, any, ctx->opts.count_visits != 0, ctx->stream));
+			ctx->queued_kernel = p.kernel;
+		}
 	}
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
 	ctx->stats.last_kernel_launches = sort ? 3 : (detect ? 2 : 1);
@@ -321,16 +333,18 @@ int finish_timing(mrt_ctx *ctx, bool h2d, bool sorted, bool d2h)
 	if (sorted) { HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3])); ctx->stats.last_sort_ms = ms; }
 	HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[3], ctx->ev[4])); ctx->stats.last_trace_ms = ms;
 	if (d2h) { HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev[4], ctx->ev[5])); ctx->stats.last_d2h_ms = ms; }
+	// which kernel did the work: the stream has been waited for, so detect_grid_kernel's words are in h_auto
+	ctx->stats.detected_grid_w = ctx->queued_detect ? ctx->h_auto[0] : 0u;
+	ctx->stats.reserved = ctx->queued_detect ? ctx->h_auto[3] : 0u; // 1: the "coherent" batch was judged incoherent
+	ctx->stats.last_kernel = (ctx->queued_detect && ctx->queued_alt_kernel && ctx->h_auto[3]) ? ctx->queued_alt_kernel : ctx->queued_kernel;
 	if (ctx->opts.count_visits) {
-		unsigned long long c[8];
+		unsigned long long c[mrt::kNumCounters];
 		HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
-		ctx->stats.tri_tests += c[1]; ctx->stats.bvh_nodes_visited += c[2]; ctx->stats.hits += c[3];
-		if ((uint32_t)c[4] > ctx->stats.max_stack_depth) ctx->stats.max_stack_depth = (uint32_t)c[4];
-		ctx->stats.dead_pops += c[5];
-		uint32_t g[4] = {0, 0, 0, 0};
-		if (ctx->stats.last_kernel_launches == 2) HIP_TRY(ctx, hipMemcpy(g, ctx->d_counters + 8, sizeof(g), hipMemcpyDeviceToHost));
-		ctx->stats.detected_grid_w = g[0];
-		ctx->stats.reserved = g[3]; // 1: the "coherent" batch was judged incoherent (lane kernel takes it)
+		ctx->stats.tri_tests += c[mrt::kCntTris]; ctx->stats.bvh_nodes_visited += c[mrt::kCntNodes]; ctx->stats.hits += c[mrt::kCntHits];
+		if ((uint32_t)c[mrt::kCntMaxStack] > ctx->stats.max_stack_depth) ctx->stats.max_stack_depth = (uint32_t)c[mrt::kCntMaxStack];
+		ctx->stats.dead_pops += c[mrt::kCntDeadPops];
+		ctx->stats.wave_node_fetches += c[mrt::kCntWaveNodeFetch]; ctx->stats.wave_tri_fetches += c[mrt::kCntWaveTriFetch];
+		ctx->stats.leaf_box_checks += c[mrt::kCntLeafBoxChecks];
 	}
 	return MRT_OK;
 }
@@ -403,6 +417,17 @@ extern "C" {
 
 uint32_t mrt_version(void) { return (MRT_VERSION_MAJOR << 16) | MRT_VERSION_MINOR; }
 
+uint32_t mrt_struct_size(uint32_t which)
+{
+	switch (which) {
+		case 0: return (uint32_t)sizeof(mrt_options);
+		case 1: return (uint32_t)sizeof(mrt_camera);
+		case 2: return (uint32_t)sizeof(mrt_stats);
+		case 3: return (uint32_t)sizeof(mrt_instance);
+		default: return 0u;
+	}
+}
+
 const char *mrt_status_string(int s)
 {
 	switch (s) {
@@ -420,6 +445,24 @@ const char *mrt_status_string(int s)
 	}
 }
 
+const char *mrt_kernel_name(uint32_t kernel)
+{
+	switch (kernel) {
+		case MRT_KERNEL_LANE: return "trace_lane_kernel";
+		case MRT_KERNEL_PACKET: return "trace_packet_kernel";
+		case MRT_KERNEL_PACKET_ASM: return "trace_packet_asm_kernel";
+		case MRT_KERNEL_PACKET_DUAL: return "trace_packet_dual_kernel";
+		case MRT_KERNEL_LANE_PERSISTENT: return "trace_lane_persistent_kernel<2>";
+		case MRT_KERNEL_LANE4_PERSISTENT: return "trace_lane_persistent_kernel<4>";
+		case MRT_KERNEL_LANE8_PERSISTENT: return "trace_lane_persistent_kernel<8>";
+		case MRT_KERNEL_TWO_LEVEL: return "trace_two_level_kernel";
+		case MRT_KERNEL_TWO_LEVEL_PACKET: return "trace_two_level_packet_kernel";
+		case MRT_KERNEL_TWO_LEVEL_PERSISTENT: return "trace_lane_persistent_kernel<2, two-level>";
+		case MRT_KERNEL_TWO_LEVEL_PERSISTENT8: return "trace_lane_persistent_kernel<8, two-level>";
+		default: return "?";
+	}
+}
+
 const char *mrt_last_error(const mrt_ctx *ctx) { return ctx ? ctx->err : "null context"; }
 
 int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
@@ -427,6 +470,7 @@ int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
 	if (!out) return MRT_ERR_INVALID;
 	*out = nullptr;
 	if (opts && opts->struct_size != sizeof(mrt_options)) return MRT_ERR_INVALID;
+	if (opts && (opts->kernel > MRT_KERNEL_PACKET_DUAL || opts->kernel == 3u || opts->kernel == 4u)) return MRT_ERR_INVALID; // 3, 4: retired ids
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || device_ordinal < 0 || device_ordinal >= n) return MRT_ERR_NO_DEVICE;
 	mrt_ctx *ctx = new (std::nothrow) mrt_ctx();
@@ -443,9 +487,12 @@ int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
 	}
 	ctx->stream = ctx->own_stream;
 	for (auto &e : ctx->ev) if (hipEventCreate(&e) != hipSuccess) return bail(MRT_ERR_HIP);
-	// [0..7] visit counters, [8..15] detected grid, [16..1040] detect_grid_kernel scratch (masks + ticket)
-	if (hipMalloc(&ctx->d_counters, (16 + 1026 + 128) * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_OOM);
-	if (hipMemset(ctx->d_counters, 0, (16 + 1026 + 128) * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_HIP);
+	// visit counters, detected grid, detect_grid_kernel scratch, ray counters: the layout is in mrt_internal.h
+	if (hipMalloc(&ctx->d_counters, mrt::kCounterWords * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_OOM);
+	if (hipMemset(ctx->d_counters, 0, mrt::kCounterWords * sizeof(unsigned long long)) != hipSuccess) return bail(MRT_ERR_HIP);
+	if (hipHostMalloc((void **)&ctx->h_auto, 64, hipHostMallocMapped) != hipSuccess) return bail(MRT_ERR_OOM);
+	std::memset(ctx->h_auto, 0, 64);
+	if (hipHostGetDevicePointer((void **)&ctx->d_auto_host, ctx->h_auto, 0) != hipSuccess) return bail(MRT_ERR_HIP);
 	*out = ctx;
 	return MRT_OK;
 }
@@ -459,6 +506,7 @@ void mrt_destroy(mrt_ctx *ctx)
 	release(ctx->rays); release(ctx->hits); release(ctx->keys_in); release(ctx->keys_out);
 	release(ctx->idx_in); release(ctx->idx_out); release(ctx->sort_tmp); release(ctx->overflow);
 	if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+	if (ctx->h_auto) (void)hipHostFree(ctx->h_auto);
 	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : ctx->pipe_ev) (void)hipEventDestroy(e);
 	if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
@@ -830,7 +878,7 @@ int mrt_cast(mrt_ctx *ctx, const void *rays, void *hits, uint64_t count, uint32_
 	}
 	int rc = enqueue_cast(ctx, rays, hits_dev ? hits : nullptr, count, query_mask, mode, flags, &d_hits);
 	if (rc) return rc;
-	if (flags & MRT_FLAG_ASYNC) return MRT_OK; // queued on the context's stream; no timing
+	if (flags & MRT_FLAG_ASYNC) { ctx->stats.last_kernel = 0; return MRT_OK; } // queued on the context's stream; no timing
 	if (!hits_dev) {
 		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, count * hit_stride(flags, mode), hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
@@ -876,6 +924,10 @@ int mrt_has_pending(const mrt_ctx *ctx) { return ctx && ctx->pending ? 1 : 0; }
 static int grid_params(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t grid_h, uint32_t y0, uint32_t y1, mrt::TraceParams &p)
 {
 	if (!cam || grid_w == 0 || grid_h == 0 || y0 > y1 || y1 > grid_h) return fail(ctx, MRT_ERR_INVALID, "bad grid");
+	if (cam->kind > MRT_CAMERA_ORTHOGRAPHIC) return fail(ctx, MRT_ERR_INVALID, "bad camera kind");
+	// RayCamera::generate_rays asserts the resolution the camera was set up for (ray_camera.h:150-152)
+	if (cam->kind != MRT_CAMERA_DEBUG_GRID && (cam->inv_w != 1.0f / (float)grid_w || cam->inv_h != 1.0f / (float)grid_h))
+		return fail(ctx, MRT_ERR_INVALID, "camera was set up for another resolution");
 	base_params(ctx, p);
 	p.cam = *cam; p.grid_w = grid_w; p.grid_h = grid_h; p.y0 = y0; p.rows = y1 - y0;
 	p.tiles_x = (grid_w + (1u << p.tile_w_log2) - 1u) >> p.tile_w_log2;
@@ -921,10 +973,11 @@ int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t
 	p.lane_map = ctx->opts.grid_tile == 1 ? mrt::MAP_LINEAR : mrt::MAP_TILE8X8;
 	p.kernel = pick_kernel(ctx, true);
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
+	ctx->queued_kernel = p.kernel; ctx->queued_alt_kernel = 0; ctx->queued_detect = false;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
-	if (flags & MRT_FLAG_ASYNC) { ctx->stats.rays_cast += p.count; return MRT_OK; }
+	if (flags & MRT_FLAG_ASYNC) { ctx->stats.rays_cast += p.count; ctx->stats.last_kernel = 0; return MRT_OK; }
 	if (!hits_dev) {
 		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, p.count * hs, hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
@@ -952,8 +1005,9 @@ int mrt_cast_tiled(mrt_ctx *ctx, const mrt_ray32 *d_rays, mrt_hit32 *d_hits,
 	p.grid_w = grid_w; p.grid_h = rows; p.y0 = 0; p.rows = rows;
 	p.tiles_x = (grid_w + (1u << p.tile_w_log2) - 1u) >> p.tile_w_log2;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream));
+	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
+	ctx->queued_kernel = p.kernel; ctx->queued_alt_kernel = 0; ctx->queued_detect = false;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	ctx->stats.last_kernel_launches = 1; ctx->stats.rays_cast += p.count;

@@ -88,6 +88,49 @@ extern "C" int mrt_camera_look(mrt_camera *cam, const float origin[3], const flo
 	for (int k = 0; k < 3; k++) { cam->origin[k] = origin[k]; cam->fwd[k] = fwd[k]; cam->right[k] = right[k]; cam->up[k] = up[k]; }
 	cam->half_w = half_w; cam->half_h = half_h;
 	cam->t_min = 0.001f; cam->t_max = FLT_MAX; // Ray(origin, dir) defaults, src/core/ray.h:59
+	cam->kind = MRT_CAMERA_DEBUG_GRID;
+	cam->inv_w = 1.0f / (float)grid_w; cam->inv_h = 1.0f / (float)grid_h; // unused by this kind
+	cam->jitter_x = cam->jitter_y = 0.5f;
+	cam->reserved[0] = cam->reserved[1] = cam->reserved[2] = 0u;
+	return MRT_OK;
+}
+
+// RayCamera::setup (ray_camera.h:50-76): origin, basis, 1 / resolution; columns 0 / 1 / 2 of the basis
+static void ray_camera_common(mrt_camera *cam, const float origin[3], const float basis[9], uint32_t width, uint32_t height)
+{
+	for (int k = 0; k < 3; k++) {
+		cam->origin[k] = origin[k];
+		cam->right[k] = basis[3 * k + 0]; cam->up[k] = basis[3 * k + 1]; cam->fwd[k] = basis[3 * k + 2];
+	}
+	cam->inv_w = 1.0f / (float)width; cam->inv_h = 1.0f / (float)height;
+	cam->jitter_x = cam->jitter_y = 0.5f;
+	cam->t_min = 0.001f; cam->t_max = FLT_MAX;
+	cam->reserved[0] = cam->reserved[1] = cam->reserved[2] = 0u;
+}
+
+// RayCamera::_setup_perspective, ray_camera.h:208-218: Math_PI is a double constant, so the tangent is
+// taken in double and rounded once; half_w = tan_half * aspect in float.
+extern "C" int mrt_camera_perspective(mrt_camera *cam, const float origin[3], const float basis[9],
+		uint32_t width, uint32_t height, float fov_degrees)
+{
+	if (!cam || !origin || !basis || width == 0 || height == 0 || !(fov_degrees > 0.0f)) return MRT_ERR_INVALID;
+	ray_camera_common(cam, origin, basis, width, height);
+	const float aspect = (float)width / (float)height;
+	const float tan_half = (float)std::tan((double)(fov_degrees * 0.5f) * (3.1415926535897932384626433833 / 180.0));
+	cam->half_w = tan_half * aspect; cam->half_h = tan_half;
+	cam->kind = MRT_CAMERA_PERSPECTIVE;
+	return MRT_OK;
+}
+
+// RayCamera::_setup_orthographic, ray_camera.h:220-230: size = full vertical extent in world units
+extern "C" int mrt_camera_orthographic(mrt_camera *cam, const float origin[3], const float basis[9],
+		uint32_t width, uint32_t height, float size)
+{
+	if (!cam || !origin || !basis || width == 0 || height == 0 || !(size > 0.0f)) return MRT_ERR_INVALID;
+	ray_camera_common(cam, origin, basis, width, height);
+	const float aspect = (float)width / (float)height;
+	cam->half_h = size * 0.5f; cam->half_w = cam->half_h * aspect;
+	cam->kind = MRT_CAMERA_ORTHOGRAPHIC;
 	return MRT_OK;
 }
 

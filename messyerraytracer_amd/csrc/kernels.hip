@@ -98,20 +98,44 @@ __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t 
 	return true;
 }
 
-// Primary-ray grid: RayTracerDebug::cast_debug_rays, src/godot/raytracer_debug.cpp:585-596.
-// Basis / half extents come precomputed from the host (mrt_camera_look, :573-583).
+// Primary-ray grids.  MRT_CAMERA_DEBUG_GRID: RayTracerDebug::cast_debug_rays, src/godot/raytracer_debug.cpp:585-596
+// (basis / half extents precomputed on the host, mrt_camera_look, :573-583).  MRT_CAMERA_PERSPECTIVE /
+// _ORTHOGRAPHIC: RayCamera::_generate_perspective / _generate_orthographic, src/modules/graphics/
+// ray_camera.h:234-273 (v flipped; Basis::xform = one dot product per row, summed left to right; the
+// jittered form of :106-122 with the pixel centre 0.5 as the default offset).  Plain float operations in the
+// reference's order (nothing is contracted): bit-identical to the host loops.
 __device__ __forceinline__ void grid_ray(const TraceParams &p, uint32_t px, uint32_t py, RayRegs &r)
 {
 	const mrt_camera &c = p.cam;
-	const float u = (2.0f * ((float)px + 0.5f) / (float)p.grid_w - 1.0f) * c.half_w;
-	const float v = (2.0f * ((float)(py + p.y0) + 0.5f) / (float)p.grid_h - 1.0f) * c.half_h;
-	float dx = c.fwd[0] + c.right[0] * u + c.up[0] * v;
-	float dy = c.fwd[1] + c.right[1] * u + c.up[1] * v;
-	float dz = c.fwd[2] + c.right[2] * u + c.up[2] * v;
+	float dx, dy, dz;
+	r.ox = c.origin[0]; r.oy = c.origin[1]; r.oz = c.origin[2];
+	if (c.kind == MRT_CAMERA_DEBUG_GRID) {
+		const float u = (2.0f * ((float)px + 0.5f) / (float)p.grid_w - 1.0f) * c.half_w;
+		const float v = (2.0f * ((float)(py + p.y0) + 0.5f) / (float)p.grid_h - 1.0f) * c.half_h;
+		dx = c.fwd[0] + c.right[0] * u + c.up[0] * v;
+		dy = c.fwd[1] + c.right[1] * u + c.up[1] * v;
+		dz = c.fwd[2] + c.right[2] * u + c.up[2] * v;
+	} else {
+		const float u = (2.0f * ((float)px + c.jitter_x) * c.inv_w) - 1.0f;
+		const float v = 1.0f - (2.0f * ((float)(py + p.y0) + c.jitter_y) * c.inv_h);
+		if (c.kind == MRT_CAMERA_PERSPECTIVE) {
+			const float vx = u * c.half_w, vy = v * c.half_h; // view_dir = (vx, vy, -1)
+			dx = c.right[0] * vx + c.up[0] * vy + c.fwd[0] * -1.0f;
+			dy = c.right[1] * vx + c.up[1] * vy + c.fwd[1] * -1.0f;
+			dz = c.right[2] * vx + c.up[2] * vy + c.fwd[2] * -1.0f;
+		} else { // parallel rays: the direction is -column 2 as it stands (Ray(ray_origin, forward_): not normalised)
+			const float sv = v * c.half_h, su = u * c.half_w;
+			r.ox = (c.origin[0] + c.up[0] * sv) + c.right[0] * su;
+			r.oy = (c.origin[1] + c.up[1] * sv) + c.right[1] * su;
+			r.oz = (c.origin[2] + c.up[2] * sv) + c.right[2] * su;
+			r.dx = -c.fwd[0]; r.dy = -c.fwd[1]; r.dz = -c.fwd[2];
+			r.t_min = c.t_min; r.t_max = c.t_max;
+			return;
+		}
+	}
 	const float l2 = dx * dx + dy * dy + dz * dz;
 	if (l2 == 0.0f) { dx = dy = dz = 0.0f; }
 	else { const float l = __builtin_sqrtf(l2); dx /= l; dy /= l; dz /= l; }
-	r.ox = c.origin[0]; r.oy = c.origin[1]; r.oz = c.origin[2];
 	r.dx = dx; r.dy = dy; r.dz = dz;
 	r.t_min = c.t_min; r.t_max = c.t_max;
 }
@@ -314,17 +338,21 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 	finish_ray(p, ray_idx, r, best_t, best_u, best_v, best_slot);
 
 	if (COUNT) {
-		atomicAdd(&p.counters[0], 1ull);
-		atomicAdd(&p.counters[1], (unsigned long long)n_tris);
-		atomicAdd(&p.counters[2], (unsigned long long)n_nodes);
-		if (best_slot != 0xFFFFFFFFu) atomicAdd(&p.counters[3], 1ull);
-		atomicMax(&p.counters[4], (unsigned long long)max_sp);
+		atomicAdd(&p.counters[kCntRays], 1ull);
+		atomicAdd(&p.counters[kCntTris], (unsigned long long)n_tris);
+		atomicAdd(&p.counters[kCntNodes], (unsigned long long)n_nodes);
+		if (best_slot != 0xFFFFFFFFu) atomicAdd(&p.counters[kCntHits], 1ull);
+		atomicMax(&p.counters[kCntMaxStack], (unsigned long long)max_sp);
+		// one lane = one ray: every node step is a (divergent) node fetch, every test a triangle row
+		atomicAdd(&p.counters[kCntWaveNodeFetch], (unsigned long long)n_nodes);
+		atomicAdd(&p.counters[kCntWaveTriFetch], (unsigned long long)n_tris);
 	}
 }
 
 #include "lane_persistent_kernel.h"
 #include "packet_kernel.h"
 #include "packet_asm_kernel.h"
+#include "packet_dual_kernel.h"
 #include "two_level_kernel.h"
 
 // ---- standalone ray generation (mrt_generate_grid) ---------------------------------
@@ -401,7 +429,7 @@ __device__ __forceinline__ void ray_dir(const void *rays, uint32_t in_fmt, uint6
 	}
 }
 __global__ __launch_bounds__(MRT_DETECT_THREADS) void detect_grid_kernel(const void *rays, uint32_t in_fmt, uint64_t count,
-		uint32_t tile_w_log2, unsigned long long *scratch, uint32_t *out)
+		uint32_t tile_w_log2, unsigned long long *scratch, uint32_t *out, uint32_t *host_out)
 {
 	__shared__ uint32_t first, second, is_last;
 	const uint32_t m = (uint32_t)(count < (uint64_t)MRT_DETECT_MAX_RAYS ? count : (uint64_t)MRT_DETECT_MAX_RAYS);
@@ -464,16 +492,18 @@ __global__ __launch_bounds__(MRT_DETECT_THREADS) void detect_grid_kernel(const v
 		// somewhere else, the batch goes to the lane kernel (out[3] = 1) instead of packets
 		const unsigned long long n_wide = __hip_atomic_load(&scratch[1025], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		out[3] = (n_wide * 8ull > (unsigned long long)m) ? 1u : 0u;
+		// the same four words to host-mapped memory: read by the host after it has waited for the stream
+		if (host_out) { host_out[0] = out[0]; host_out[1] = out[1]; host_out[2] = out[2]; host_out[3] = out[3]; }
 		scratch[1024] = 0ull; scratch[1025] = 0ull; // ticket / counter for the next launch (stream ordered)
 	}
 }
 
 hipError_t launch_detect_grid(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t tile_w_log2,
-		unsigned long long *scratch, uint32_t *out, hipStream_t stream)
+		unsigned long long *scratch, uint32_t *out, uint32_t *host_out, hipStream_t stream)
 {
 	const uint32_t m = (uint32_t)(count < (uint64_t)MRT_DETECT_MAX_RAYS ? count : (uint64_t)MRT_DETECT_MAX_RAYS);
 	const uint32_t blocks = (m + MRT_DETECT_THREADS - 1) / MRT_DETECT_THREADS;
-	hipLaunchKernelGGL(detect_grid_kernel, dim3(blocks), dim3(MRT_DETECT_THREADS), 0, stream, rays, in_fmt, count, tile_w_log2, scratch, out);
+	hipLaunchKernelGGL(detect_grid_kernel, dim3(blocks), dim3(MRT_DETECT_THREADS), 0, stream, rays, in_fmt, count, tile_w_log2, scratch, out, host_out);
 	return hipGetLastError();
 }
 
@@ -566,8 +596,8 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 	if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
 	dim3 grid((uint32_t)blocks), wg(MRT_WG);
 	if (p.kernel == MRT_KERNEL_TWO_LEVEL_PACKET) { // two-level scene, coherent batch: one wave per packet
-		if (any_hit) hipLaunchKernelGGL((trace_two_level_packet_kernel<true>), grid, wg, 0, stream, p);
-		else hipLaunchKernelGGL((trace_two_level_packet_kernel<false>), grid, wg, 0, stream, p);
+		if (any_hit) hipLaunchKernelGGL((trace_two_level_packet_kernel<true>), grid, wg, p.extra_lds, stream, p);
+		else hipLaunchKernelGGL((trace_two_level_packet_kernel<false>), grid, wg, p.extra_lds, stream, p);
 		return hipGetLastError();
 	}
 	if (p.kernel == MRT_KERNEL_TWO_LEVEL) { // two-level scene: one lane per ray, per-lane LDS stack
@@ -576,10 +606,23 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		else hipLaunchKernelGGL((trace_two_level_kernel<false>), grid, wg, lds2, stream, p);
 		return hipGetLastError();
 	}
-	// counting builds use the C++ packet kernel, and so do scenes whose node offsets pass the asm loop's 32 bits
-	if (p.kernel == MRT_KERNEL_PACKET_ASM && !count && p.n_nodes < kAsmNodeLimit) {
-		if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true>), grid, wg, 0, stream, p);
-		else hipLaunchKernelGGL((trace_packet_asm_kernel<false>), grid, wg, 0, stream, p);
+	if (p.kernel == MRT_KERNEL_PACKET_DUAL) { // two packets per wave: half the waves
+		const uint64_t dblocks = (threads + 2u * MRT_WG - 1) / (2u * MRT_WG);
+		dim3 dgrid((uint32_t)dblocks);
+		if (count) {
+			if (any_hit) hipLaunchKernelGGL((trace_packet_dual_kernel<true, true>), dgrid, wg, p.extra_lds, stream, p);
+			else hipLaunchKernelGGL((trace_packet_dual_kernel<false, true>), dgrid, wg, p.extra_lds, stream, p);
+		} else if (any_hit) hipLaunchKernelGGL((trace_packet_dual_kernel<true>), dgrid, wg, p.extra_lds, stream, p);
+		else hipLaunchKernelGGL((trace_packet_dual_kernel<false>), dgrid, wg, p.extra_lds, stream, p);
+		return hipGetLastError();
+	}
+	// scenes whose node offsets pass the asm loop's 32 bits use the C++ packet kernel
+	if (p.kernel == MRT_KERNEL_PACKET_ASM && p.n_nodes < kAsmNodeLimit) {
+		if (count) {
+			if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true, true>), grid, wg, p.extra_lds, stream, p);
+			else hipLaunchKernelGGL((trace_packet_asm_kernel<false, true>), grid, wg, p.extra_lds, stream, p);
+		} else if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true>), grid, wg, p.extra_lds, stream, p);
+		else hipLaunchKernelGGL((trace_packet_asm_kernel<false>), grid, wg, p.extra_lds, stream, p);
 		return hipGetLastError();
 	}
 	if (p.kernel == MRT_KERNEL_PACKET || p.kernel == MRT_KERNEL_PACKET_ASM) {

@@ -75,6 +75,19 @@ struct alignas(16) Dev8Node {
 };
 static_assert(sizeof(Dev8Node) == 128, "Dev8Node must be 128 bytes");
 
+// ---- the context's counter block (unsigned long long words; mrt_ctx::d_counters) ----
+// [0, kNumCounters): visit counters of the counting kernel variants (mrt_options.count_visits)
+constexpr int kCntRays = 0, kCntTris = 1, kCntNodes = 2, kCntHits = 3, kCntMaxStack = 4, kCntDeadPops = 5;
+constexpr int kCntWaveNodeFetch = 6; // node fetches as the hardware sees them: one per wave step (packet kernels), one per lane step
+                                     // = one divergent 64-/128-byte line (lane kernels)
+constexpr int kCntWaveTriFetch = 7;  // triangle rows fetched: one per wave step (packet kernels), one per lane test (lane kernels)
+constexpr int kCntLeafBoxChecks = 8; // 8-wide kernel: exact leaf boxes read for candidate hits
+constexpr int kNumCounters = 16;
+constexpr int kAutoGridOff = kNumCounters;         // 8 words: what detect_grid_kernel found (4 x u32 used)
+constexpr int kDetectScratchOff = kAutoGridOff + 8; // 1026 words: jump masks + ticket + wide-neighbour count
+constexpr int kNextRayOff = kDetectScratchOff + 1026; // 128 words: 8 ray counters of the persistent kernels, 16 words apart
+constexpr int kCounterWords = kNextRayOff + 128;
+
 constexpr uint32_t kSentinel = 0x7FFFFFFFu;
 constexpr uint32_t kLeafBit = 0x80000000u;
 constexpr uint32_t kLastInLeaf = 1u;
@@ -97,7 +110,7 @@ struct TraceParams {
 	const void *rays;          // IN_RAY32 / IN_HOST60 (device)
 	void *hits;                // device
 	const uint32_t *perm;      // optional: lane g traces ray perm[g], writes hits[perm[g]]
-	unsigned long long *counters; // COUNT variants: rays, tri_tests, node_visits, hits, max_stack
+	unsigned long long *counters; // COUNT variants: the kCnt* words above
 	const uint32_t *auto_grid; // MAP_AUTO: {row width (0 = none), rows, tiles_x, incoherent} written by detect_grid_kernel
 	const uint32_t *skip_flag; // optional: the whole launch returns at once when *skip_flag == skip_when
 	uint32_t skip_when;        // (a "coherent" batch that is not: the packet launch yields to the lane launch)
@@ -113,6 +126,7 @@ struct TraceParams {
 	uint32_t xcd_swizzle;      // 1: remap blockIdx so each XCD owns a contiguous band
 	uint32_t n_tris;           // rows in tri_hot / tri_cold (token validation)
 	uint32_t n_nodes;          // rows in nodes (the hand-written node loop addresses them with a 32-bit byte offset)
+	uint32_t extra_lds;        // experiments: dynamic LDS bytes added per workgroup of the packet kernels (occupancy sweeps)
 	mrt_camera cam;
 };
 
@@ -152,10 +166,11 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 // first slot of a run of DevInstance rows (leaf order; the last row of a leaf has flags & 1).
 constexpr uint32_t kAsmNodeLimit = 1u << 26;     // packet_asm_kernel.h: node index * 64 must fit 32 bits
 constexpr uint32_t kInstanceReturn = 0x7FFFFFFEu; // stack marker: back from a BLAS to the TLAS walk
-constexpr uint32_t MRT_KERNEL_TWO_LEVEL = 100u;    // internal kernel ids (TraceParams.kernel): one lane per ray,
-constexpr uint32_t MRT_KERNEL_TWO_LEVEL_PACKET = 101u; // one wave per 64-ray packet (coherent batches)
-constexpr uint32_t MRT_KERNEL_TWO_LEVEL_PERSISTENT = 102u; // resident waves, node / leaf phases (large incoherent batches)
-constexpr uint32_t MRT_KERNEL_TWO_LEVEL_PERSISTENT8 = 103u; // the same with 8-wide compressed BLAS nodes
+// kernel ids of two-level scenes (TraceParams.kernel; the values of the public enum, include/mrt_hip.h):
+// MRT_KERNEL_TWO_LEVEL one lane per ray, _PACKET one wave per 64-ray packet (coherent batches), _PERSISTENT
+// resident waves with node / leaf phases (large incoherent batches), _PERSISTENT8 the same with 8-wide BLAS nodes
+using ::MRT_KERNEL_TWO_LEVEL; using ::MRT_KERNEL_TWO_LEVEL_PACKET; using ::MRT_KERNEL_TWO_LEVEL_PERSISTENT;
+using ::MRT_KERNEL_TWO_LEVEL_PERSISTENT8;
 struct alignas(16) DevInstance {
 	float inv[12];      // world -> object, rows {m00 m01 m02 tx}: o' = M o + t, d' = M d (no renormalisation: t stays world-parameterised)
 	float basis[9];     // object -> world 3x3 (normals: normalize(basis n))

@@ -101,8 +101,8 @@ __device__ __forceinline__ void packet_traverse(const TraceParams &p, const RayR
 				const float4 *t3 = hot + (size_t)slot * 3u; // uniform address
 				const float4 q0 = t3[0], q1 = t3[1], q2 = t3[2];
 				last = (__float_as_uint(q2.w) & kLastInLeaf) != 0u;
+				if (COUNT) n_tris++; // a triangle row fetched (its test is skipped for layers outside the query mask)
 				if ((__float_as_uint(q1.w) & p.query_mask) != 0u) {
-					if (COUNT) n_tris++;
 					// ray_triangle, glsl:105-131 == Triangle::intersect, src/core/triangle.h:56-105
 					const float pvx = fma_(r.dy, q2.z, -(r.dz * q2.y));
 					const float pvy = fma_(r.dz, q2.x, -(r.dx * q2.z));
@@ -141,6 +141,22 @@ __device__ __forceinline__ void packet_traverse(const TraceParams &p, const RayR
 	if (best_id_io) *best_id_io = best_id;
 }
 
+// Counters of a packet walk: node steps and triangle rows are per PACKET (wave-uniform n_nodes, n_tris); the
+// per-ray words charge every wave step to every live lane (kCntNodes, kCntTris), the fetch words count it once.
+__device__ __forceinline__ void packet_count(const TraceParams &p, uint32_t n_nodes, uint32_t n_tris, uint32_t n_dead, bool hit,
+		unsigned long long live)
+{
+	atomicAdd(&p.counters[kCntRays], 1ull);
+	atomicAdd(&p.counters[kCntTris], (unsigned long long)n_tris);
+	atomicAdd(&p.counters[kCntNodes], (unsigned long long)n_nodes);
+	if (hit) atomicAdd(&p.counters[kCntHits], 1ull);
+	atomicAdd(&p.counters[kCntDeadPops], (unsigned long long)n_dead);
+	if ((threadIdx.x & (MRT_WAVE - 1)) == (uint32_t)__builtin_ctzll(live)) {
+		atomicAdd(&p.counters[kCntWaveNodeFetch], (unsigned long long)n_nodes);
+		atomicAdd(&p.counters[kCntWaveTriFetch], (unsigned long long)n_tris);
+	}
+}
+
 template <bool ANY_HIT, bool COUNT>
 __global__ __launch_bounds__(MRT_WG) void trace_packet_kernel(const TraceParams p)
 {
@@ -176,11 +192,5 @@ __global__ __launch_bounds__(MRT_WG) void trace_packet_kernel(const TraceParams 
 
 	finish_ray(p, ray_idx, r, best_t, best_u, best_v, best_slot);
 
-	if (COUNT) { // wave-level counts: each wave-step is charged to every live lane
-		atomicAdd(&p.counters[0], 1ull);
-		atomicAdd(&p.counters[1], (unsigned long long)n_tris);
-		atomicAdd(&p.counters[2], (unsigned long long)n_nodes);
-		if (best_slot != 0xFFFFFFFFu) atomicAdd(&p.counters[3], 1ull);
-		atomicAdd(&p.counters[5], (unsigned long long)n_dead);
-	}
+	if (COUNT) packet_count(p, n_nodes, n_tris, n_dead, best_slot != 0xFFFFFFFFu, live);
 }

@@ -230,13 +230,13 @@ __global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_waves_per_eu(7, 8))) 
 						sz = __ballot(!dead && safe_inv(ro.dz) < 0.0f);
 				const bool uniform = (sx == 0ull || sx == alive) && (sy == 0ull || sy == alive) && (sz == 0ull || sz == alive);
 				const int oct = uniform ? ((sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0)) : 8;
+				uint32_t nn = 0, nt = 0, nd = 0; // (counters of the flat counting builds: unused here)
 				if (oct == 8 || p.n_nodes >= kAsmNodeLimit) { // mixed octants, or node offsets beyond the asm loop's 32 bits
-					uint32_t nn = 0, nt = 0, nd = 0;
 					packet_traverse<8, ANY_HIT, false>(p, ro, bstack, best_t, best_u, best_v, best_slot, nn, nt, nd, root, id_base, &best_id, dead);
 				} else {
 					*(volatile uint32_t *)&bstack[0] = kSentinel;
 					const uint32_t bsp = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(bstack + 4);
-#define MRT_PKTB(O) case O: packet_traverse_asm<O, ANY_HIT>(p, ro, bsp, best_t, best_u, best_v, best_slot, root, id_base, &best_id, dead); break;
+#define MRT_PKTB(O) case O: packet_traverse_asm<O, ANY_HIT>(p, ro, bsp, best_t, best_u, best_v, best_slot, nn, nt, root, id_base, &best_id, dead); break;
 					switch (oct) { MRT_PKTB(0) MRT_PKTB(1) MRT_PKTB(2) MRT_PKTB(3) MRT_PKTB(4) MRT_PKTB(5) MRT_PKTB(6) MRT_PKTB(7) }
 #undef MRT_PKTB
 				}

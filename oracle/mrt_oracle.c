@@ -536,6 +536,53 @@ void orc_grid_rays(const float origin[3], const float forward[3], uint32_t w, ui
 }
 
 /* ------------------------------------------------------------------------- */
+/* RayCamera grids: src/modules/graphics/ray_camera.h                          */
+/*   setup :50-76 (inv_w, inv_h), _setup_perspective :208-218 (Math_PI is a    */
+/*   double: tangent in double, rounded once), _setup_orthographic :220-230,   */
+/*   _generate_perspective :234-251, _generate_orthographic :255-273,          */
+/*   generate_ray_jittered :106-122 (jx = jy = 0.5 is the pixel centre).       */
+/* basis: row-major 3x3 = Godot's Basis rows; Basis::xform(v) = one dot per    */
+/* row, x*v.x + y*v.y + z*v.z summed left to right.  ortho != 0: `param` is    */
+/* Camera3D::size, else the vertical field of view in degrees.                 */
+/* ------------------------------------------------------------------------- */
+void orc_ray_camera_rays(const float origin[3], const float basis[9], uint32_t w, uint32_t h, float param, int ortho,
+		float jx, float jy, uint32_t y0, uint32_t y1, orc_ray32 *out)
+{
+	const float inv_w = 1.0f / (float)w, inv_h = 1.0f / (float)h;
+	const float aspect = (float)w / (float)h;
+	float half_w, half_h;
+	if (ortho) { half_h = param * 0.5f; half_w = half_h * aspect; }
+	else {
+		const float tan_half = (float)tan((double)(param * 0.5f) * (3.1415926535897932384626433833 / 180.0));
+		half_w = tan_half * aspect; half_h = tan_half;
+	}
+	const float col0[3] = { basis[0], basis[3], basis[6] }, col1[3] = { basis[1], basis[4], basis[7] };
+	const float fwd[3] = { -basis[2], -basis[5], -basis[8] }; /* forward_ = -basis_.get_column(2) */
+	for (uint32_t y = y0; y < y1; y++) {
+		const float v = 1.0f - (2.0f * ((float)y + jy) * inv_h);
+		for (uint32_t x = 0; x < w; x++) {
+			const float u = (2.0f * ((float)x + jx) * inv_w) - 1.0f;
+			orc_ray32 *r = &out[(size_t)(y - y0) * w + x];
+			if (!ortho) {
+				const float view[3] = { u * half_w, v * half_h, -1.0f };
+				float dir[3];
+				for (int k = 0; k < 3; k++) dir[k] = basis[3 * k] * view[0] + basis[3 * k + 1] * view[1] + basis[3 * k + 2] * view[2];
+				v_normalize(dir);
+				for (int k = 0; k < 3; k++) { r->origin[k] = origin[k]; r->direction[k] = dir[k]; }
+			} else {
+				const float sv = v * half_h, su = u * half_w;
+				for (int k = 0; k < 3; k++) {
+					const float row_offset = origin[k] + col1[k] * sv; /* origin_ + up * (v * ortho_half_h_) */
+					r->origin[k] = row_offset + col0[k] * su;
+					r->direction[k] = fwd[k];
+				}
+			}
+			r->t_min = 0.001f; r->t_max = FLT_MAX;
+		}
+	}
+}
+
+/* ------------------------------------------------------------------------- */
 /* Morton key: src/dispatch/ray_sort.h:41-76                                   */
 /* ------------------------------------------------------------------------- */
 static inline uint32_t spread10(uint32_t v)

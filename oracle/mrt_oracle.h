@@ -67,6 +67,8 @@ int orc_tri_test(const orc_tri64 *tri, const orc_ray32 *ray, float *t, float *u,
 /* src/godot/raytracer_debug.cpp:572-596 */
 void orc_camera_basis(const float forward[3], uint32_t w, uint32_t h, float fov_deg,
 		float fwd[3], float right[3], float up[3], float *half_w, float *half_h);
+void orc_ray_camera_rays(const float origin[3], const float basis[9], uint32_t w, uint32_t h, float param, int ortho,
+		float jx, float jy, uint32_t y0, uint32_t y1, orc_ray32 *out);
 void orc_grid_rays(const float origin[3], const float forward[3], uint32_t w, uint32_t h, float fov_deg,
 		uint32_t y0, uint32_t y1, orc_ray32 *out);
 /* src/dispatch/ray_sort.h:41-76 */

@@ -165,6 +165,18 @@ def grid_rays(origin, forward, w, h, fov_deg, y0=0, y1=None):
     return out
 
 
+def ray_camera_rays(origin, basis, w, h, param, ortho=False, jitter=(0.5, 0.5), y0=0, y1=None):
+    """RayCamera::generate_rays (ray_camera.h:234-273): basis = 3x3 row-major camera basis; param = vertical
+    fov in degrees (perspective) or Camera3D::size (orthographic)."""
+    y1 = h if y1 is None else y1
+    out = np.zeros((y1 - y0) * w, dtype=RAY32)
+    o = (C.c_float * 3)(*origin)
+    b = (C.c_float * 9)(*np.asarray(basis, dtype=np.float32).reshape(9))
+    lib().orc_ray_camera_rays(o, b, C.c_uint32(w), C.c_uint32(h), C.c_float(param), C.c_int(1 if ortho else 0),
+                              C.c_float(jitter[0]), C.c_float(jitter[1]), C.c_uint32(y0), C.c_uint32(y1), _p(out))
+    return out
+
+
 def morton_keys(rays):
     rays = np.ascontiguousarray(rays)
     keys = np.zeros(rays.shape[0], dtype=np.uint32)

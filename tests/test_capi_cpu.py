@@ -26,9 +26,15 @@ def test_library_exports_every_declared_symbol(built):
     assert L.mrt_status_string(capi.ERR_PENDING) != L.mrt_status_string(capi.ERR_NOT_PENDING)
 
 
-def test_struct_sizes_match_reference_layouts():
-    assert C.sizeof(capi.Options) == 64
-    assert C.sizeof(capi.Camera) == 64
+def test_struct_sizes_match_reference_layouts(built):
+    # the ctypes declarations against the library's own sizeof()
+    L = capi.load()
+    from messyerraytracer_amd import types as TT
+    assert C.sizeof(capi.Options) == L.mrt_struct_size(0) == 64
+    assert C.sizeof(capi.Camera) == L.mrt_struct_size(1) == 96
+    assert C.sizeof(capi.Stats) == L.mrt_struct_size(2)
+    assert TT.INSTANCE.itemsize == L.mrt_struct_size(3) == 64
+    assert L.mrt_struct_size(99) == 0
     for dt, size in ((T.RAY32, 32), (T.HIT32, 32), (T.TRI64, 64), (T.NODE32, 32), (T.WIDE64, 64),
                      (T.HOST_RAY60, 60), (T.HOST_HIT44, 44), (T.HOST_TRI80, 80)):
         assert dt.itemsize == size
@@ -50,7 +56,8 @@ def test_null_arguments_are_rejected_not_crashed(built):
     assert L.mrt_upload_two_level_scene(None, None, 0, None, 0, 0) == capi.ERR_INVALID
     assert L.mrt_update_instances(None, None, 0) == capi.ERR_INVALID
     assert L.mrt_expand_grid_tokens(None, None, 0, 0, 0, 0, None, None, None) == capi.ERR_INVALID
-    assert C.sizeof(capi.Stats) == 80 and T.INSTANCE.itemsize == 64
+    assert L.mrt_camera_perspective(None, None, None, 0, 0, 0.0) == capi.ERR_INVALID
+    assert L.mrt_kernel_name(capi.KERNEL_PACKET_DUAL) == b"trace_packet_dual_kernel" and L.mrt_kernel_name(77) == b"?"
     L.mrt_destroy(None)  # no-op
 
 

@@ -45,6 +45,10 @@ VARIANTS = {
     "asm_fused_zorder_swz": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_order=2, xcd_swizzle=1), "fused"),
     "asm_fused_swz": (dict(kernel=capi.KERNEL_PACKET_ASM, xcd_swizzle=1), "fused"),
     "asm_fused_16x4": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_w_log2=4), "fused"),
+    "dual_fused": (dict(kernel=capi.KERNEL_PACKET_DUAL), "fused"),
+    "dual_cast": (dict(kernel=capi.KERNEL_PACKET_DUAL), "cast"),
+    "dual_fused_zorder": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=2), "fused"),
+    "dual_fused_rowmajor": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=1), "fused"),
     "auto_cast": (dict(), "cast"),
     "auto_tiled": (dict(), "tiled"),
     "persist2_linear": (dict(kernel=capi.KERNEL_LANE_PERSISTENT), "cast"),

@@ -37,10 +37,13 @@ def main():
     if os.path.exists(bench):
         summary["bench_line_under_rocprof"] = json.load(open(bench))
     counters = defaultdict(list)
+    durations = defaultdict(list)  # per counter: dispatch durations (ns) in the pass that collected it
     for f in glob.glob(os.path.join(src, "pmc_*", "*", "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             if kernel in r["Kernel_Name"]:
                 counters[r["Counter_Name"]].append(float(r["Counter_Value"]))
+                durations[r["Counter_Name"]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+                summary["kernel_name"] = r["Kernel_Name"]
                 summary.setdefault("launch", {"grid": r["Grid_Size"], "workgroup": r["Workgroup_Size"], "lds": r["LDS_Block_Size"],
                                               "vgpr": r["VGPR_Count"], "sgpr": r["SGPR_Count"], "scratch": r["Scratch_Size"]})
     pmc = {k: sum(v) / len(v) for k, v in sorted(counters.items())}
@@ -52,8 +55,28 @@ def main():
         tp = os.path.join(out_dir, "pmc_traffic.json")
         traffic = json.load(open(tp)) if os.path.exists(tp) else {}
         traffic[config] = {"hbm_bytes_per_launch": 2 * rd_raw + wr, "read_raw": rd_raw, "write": wr, "round": tag,
+                           "kernel": summary.get("kernel_name"),
                            "note": "FETCH_SIZE*1024*2 (gfx950 half-count correction) + WRITE_SIZE*1024, mean over profiled launches"}
         json.dump(traffic, open(tp, "w"), indent=1, sort_keys=True)
+    # effective shader clock of the profiled dispatches (guide, "DVFS give-back"): GRBM_GUI_ACTIVE sums the 8 XCDs
+    if "GRBM_GUI_ACTIVE" in pmc:
+        clk = [c / 8.0 / d for c, d in zip(counters["GRBM_GUI_ACTIVE"], durations["GRBM_GUI_ACTIVE"]) if d > 0]  # GHz
+        summary["effective_clock_ghz"] = sum(clk) / len(clk)
+        summary["clock_pass_kernel_ms"] = sum(durations["GRBM_GUI_ACTIVE"]) / len(clk) / 1e6
+    # VALU issue roof: a wave64 vector instruction occupies its SIMD-32 for 2 cycles (guide, cycle constants);
+    # 4 SIMDs per CU.  floor_ms = the time the launch's vector instructions need at full issue rate.
+    if "SQ_INSTS_VALU" in pmc:
+        n_simd = 256 * 4
+        clk_ghz = summary.get("effective_clock_ghz", 2.4)
+        floor_ms = pmc["SQ_INSTS_VALU"] * 2.0 / n_simd / (clk_ghz * 1e9) * 1e3
+        kt = [r for r in summary.get("kernel_stats", []) if kernel in r["Name"]]
+        kernel_ms = float(kt[0]["AverageNs"]) / 1e6 if kt else None
+        summary["valu_issue"] = {"insts_per_launch": pmc["SQ_INSTS_VALU"], "cycles_per_inst": 2, "simds": n_simd,
+                                 "clock_ghz": clk_ghz, "clock_source": "GRBM_GUI_ACTIVE pass" if "effective_clock_ghz" in summary else "max clock (no clock pass)",
+                                 "floor_ms": floor_ms, "kernel_ms": kernel_ms,
+                                 "frac": floor_ms / kernel_ms if kernel_ms else None}
+        if "SQ_INSTS_SALU" in pmc:  # one scalar unit per CU, ~1 instruction per cycle (tools/ubench/salu_rate.hip)
+            summary["salu_issue_floor_ms"] = (pmc["SQ_INSTS_SALU"] + pmc.get("SQ_INSTS_SMEM", 0.0)) / 256 / (clk_ghz * 1e9) * 1e3
     if "TCC_HIT_sum" in pmc:
         summary["l2_hit_rate"] = pmc["TCC_HIT_sum"] / (pmc["TCC_HIT_sum"] + pmc["TCC_MISS_sum"])
     if "SQ_WAVE_CYCLES" in pmc:
