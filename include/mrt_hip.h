@@ -160,6 +160,10 @@ typedef struct mrt_stats {
 	                                for 64 rays), one per lane step (= one divergent cache line) in the lane kernels */
 	uint64_t wave_tri_fetches;   /* 48-byte triangle rows fetched, counted the same way */
 	uint64_t leaf_box_checks;    /* 8-wide kernel: exact 32-byte leaf boxes read for candidate hits */
+	/* count_visits, MRT_KERNEL_PACKET_ROWS only: a clock on the walk (s_memtime, shader cycles, summed over waves) */
+	uint64_t fetch_wait_cycles;  /* between issuing a row fetch and having it (two s_memtime reads included)        */
+	uint64_t wave_cycles;        /* whole kernel body                                                             */
+	uint64_t waves;              /* waves that were clocked                                                       */
 } mrt_stats;
 
 /* mode: RayQuery::Mode, src/api/ray_query.h:54-57 / RAY_MODE spec constant,
@@ -201,8 +205,10 @@ enum {
 	MRT_KERNEL_LANE8_PERSISTENT = 8, /* the same over an 8-wide collapse with 8-bit child boxes on a per-node grid
 	                                  (compressed wide BVH, cf. the reference's cwbvh_traverse.comp.glsl), one
 	                                  128-byte line per step (default for large incoherent batches)       */
-	MRT_KERNEL_PACKET_DUAL = 9, /* two 64-ray packets per wave walked in lockstep by one hand-written node loop: twice the
-	                               node fetches in flight at the same occupancy (the packet walk is latency-bound)   */
+	MRT_KERNEL_PACKET_DUAL = 9, /* the packet walk end to end in gfx950 assembly over ONE array of 64-byte rows (nodes +
+	                               triangles), TWO packets per wave in lockstep: twice the fetches in flight at the same
+	                               occupancy (the packet walk is latency-bound); default for coherent batches        */
+	MRT_KERNEL_PACKET_ROWS = 10, /* the same walk with one packet per wave                                           */
 	/* reported in mrt_stats.last_kernel only (chosen by the library for two-level scenes, not selectable): */
 	MRT_KERNEL_TWO_LEVEL = 100, MRT_KERNEL_TWO_LEVEL_PACKET = 101, MRT_KERNEL_TWO_LEVEL_PERSISTENT = 102,
 	MRT_KERNEL_TWO_LEVEL_PERSISTENT8 = 103
@@ -213,7 +219,8 @@ const char *mrt_kernel_name(uint32_t kernel);
 typedef struct mrt_options {
 	uint32_t struct_size;     /* = sizeof(mrt_options) */
 	uint32_t kernel;          /* MRT_KERNEL_*                                        */
-	uint32_t count_visits;    /* 1: counting kernel variant fills mrt_stats counters  */
+	uint32_t count_visits;    /* 1: counting kernel variant fills mrt_stats counters; 2 (MRT_KERNEL_PACKET_ROWS): only its
+	                             sampled s_memtime clock (fetch_wait_cycles / wave_cycles / waves), nothing else counted */
 	uint32_t sort_threshold;  /* MIN_BATCH_FOR_SORTING, default 256 (ray_dispatcher.h:427) */
 	uint32_t grid_tile;       /* 0: default 8x8 lane tiling for grid casts; 1: row-major */
 	/* tuning knobs (0 = default); results never depend on them */

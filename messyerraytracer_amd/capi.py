@@ -21,7 +21,7 @@ FLAG_COHERENT, FLAG_RAYS_ON_DEVICE, FLAG_HITS_ON_DEVICE, FLAG_HOST_LAYOUT, FLAG_
 TOKEN_MISS = 0xFFFFFFFF
 BUILD_TRIS_ON_DEVICE, BUILD_SAFE_HANDOFF, BUILD_BLAS_ON_DEVICE = 1, 2, 4
 KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET = 0, 1, 2   # (3 and 4: retired experiments, ids not reused)
-KERNEL_PACKET_ASM, KERNEL_LANE_PERSISTENT, KERNEL_LANE4_PERSISTENT, KERNEL_LANE8_PERSISTENT, KERNEL_PACKET_DUAL = 5, 6, 7, 8, 9
+KERNEL_PACKET_ASM, KERNEL_LANE_PERSISTENT, KERNEL_LANE4_PERSISTENT, KERNEL_LANE8_PERSISTENT, KERNEL_PACKET_DUAL, KERNEL_PACKET_ROWS = 5, 6, 7, 8, 9, 10
 KERNEL_TWO_LEVEL, KERNEL_TWO_LEVEL_PACKET, KERNEL_TWO_LEVEL_PERSISTENT, KERNEL_TWO_LEVEL_PERSISTENT8 = 100, 101, 102, 103  # reported only
 
 # every entry point include/mrt_hip.h declares (tests check they are all exported)
@@ -62,7 +62,8 @@ class Stats(C.Structure):
                 ("last_h2d_ms", C.c_float), ("last_d2h_ms", C.c_float), ("last_kernel_launches", C.c_uint32),
                 ("max_stack_depth", C.c_uint32), ("dead_pops", C.c_uint64), ("detected_grid_w", C.c_uint32), ("reserved", C.c_uint32),
                 ("last_build_ms", C.c_float), ("last_kernel", C.c_uint32),
-                ("wave_node_fetches", C.c_uint64), ("wave_tri_fetches", C.c_uint64), ("leaf_box_checks", C.c_uint64)]
+                ("wave_node_fetches", C.c_uint64), ("wave_tri_fetches", C.c_uint64), ("leaf_box_checks", C.c_uint64),
+                ("fetch_wait_cycles", C.c_uint64), ("wave_cycles", C.c_uint64), ("waves", C.c_uint64)]
 
 
 _lib = None
@@ -228,7 +229,7 @@ class Context:
         opts = Options()
         opts.struct_size = C.sizeof(Options)
         opts.kernel = kernel
-        opts.count_visits = 1 if count_visits else 0
+        opts.count_visits = int(count_visits)
         opts.sort_threshold = sort_threshold
         opts.grid_tile = grid_tile
         opts.tile_w_log2 = tile_w_log2

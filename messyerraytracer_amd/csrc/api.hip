@@ -22,6 +22,8 @@
 namespace mrt {
 hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream);
 hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t stream);
+hipError_t launch_build_rows(const DevNode *nodes, const TriHot *hot, const TriCold *cold, uint32_t n_nodes, uint32_t n_tris,
+		void *rows, hipStream_t stream);
 hipError_t launch_expand_tokens(const TraceParams &p, const uint32_t *tokens, hipStream_t stream);
 hipError_t launch_offset_refs(DevNode *dst, const DevNode *src, uint32_t n, uint32_t node_base, uint32_t tri_base, void *stream);
 hipError_t launch_offset_refs8(Dev8Node *dst, const Dev8Node *src, uint32_t n, uint32_t node_base, uint32_t tri_base, void *stream);
@@ -53,6 +55,7 @@ struct mrt_ctx {
 	mrt::Dev4Node *d_nodes4 = nullptr; uint32_t n_nodes4 = 0;
 	mrt::Dev8Node *d_nodes8 = nullptr; uint32_t n_nodes8 = 0, stack8 = 0;
 	float *d_leaf_box = nullptr; // exact leaf boxes that go with d_nodes8
+	void *d_rows = nullptr;      // flat scenes: nodes + triangles as one array of 64-byte rows (packet_rows_kernel.h)
 	// two-level scene: d_nodes = TLAS + every BLAS, d_hot / d_cold = mesh-space triangles, d_instances in TLAS leaf order
 	mrt::DevInstance *d_instances = nullptr;
 	mrt::TwoLevelHost *two_level = nullptr; // host copy kept for mrt_update_instances
@@ -118,6 +121,8 @@ void free_scene(mrt_ctx *ctx)
 	if (ctx->d_nodes8) (void)hipFree(ctx->d_nodes8);
 	if (ctx->d_leaf_box) (void)hipFree(ctx->d_leaf_box);
 	ctx->d_leaf_box = nullptr;
+	if (ctx->d_rows) (void)hipFree(ctx->d_rows);
+	ctx->d_rows = nullptr;
 	if (ctx->d_instances) (void)hipFree(ctx->d_instances);
 	ctx->d_instances = nullptr;
 	if (ctx->two_level) { mrt::free_two_level(ctx->two_level); delete ctx->two_level; ctx->two_level = nullptr; }
@@ -144,7 +149,7 @@ uint32_t out_format(uint32_t flags, int mode)
 void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 {
 	std::memset(&p, 0, sizeof(p));
-	p.nodes = ctx->d_nodes; p.nodes4 = ctx->d_nodes4; p.nodes8 = ctx->d_nodes8; p.leaf_box = ctx->d_leaf_box; p.instances = ctx->d_instances; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold;
+	p.nodes = ctx->d_nodes; p.nodes4 = ctx->d_nodes4; p.nodes8 = ctx->d_nodes8; p.leaf_box = ctx->d_leaf_box; p.instances = ctx->d_instances; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold; p.row_array = ctx->d_rows;
 	p.stack_depth = ctx->stack_depth; p.n_tris = ctx->n_tris; p.n_nodes = ctx->n_nodes;
 	if (ctx->opts.stack_override >= ctx->depth && ctx->opts.stack_override <= 64) p.stack_depth = ctx->opts.stack_override;
 	p.counters = ctx->d_counters;
@@ -157,19 +162,39 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 	p.tile_order = ctx->opts.tile_order == 2 || (ctx->opts.tile_order == 0 && scene_bytes > (size_t)256 << 20) ? 1u : 0u;
 	if (ctx->opts.tile_order == 3) p.tile_order = 2u; // 32x32-tile super-tiles (C5: 23.3 against 23.5 ms; not the default)
 	p.extra_lds = ctx->opts.extra_lds <= 60000u ? ctx->opts.extra_lds : 60000u;
+	p.count_mode = ctx->opts.count_visits;
 	p.kernel = MRT_KERNEL_LANE; // callers pick per batch with pick_kernel()
 }
 
 // MRT_KERNEL_AUTO: packets for batches the caller declares coherent (RayQuery::coherent,
 // primary-ray grids), one lane per ray for everything else (sorted / incoherent batches).
-uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent)
+uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent, uint64_t count)
 {
 	// a two-level scene has its own pair of kernels (two_level_kernel.h)
 	if (ctx->two_level) return coherent && ctx->opts.kernel != MRT_KERNEL_LANE ? mrt::MRT_KERNEL_TWO_LEVEL_PACKET : mrt::MRT_KERNEL_TWO_LEVEL;
-	if (ctx->opts.kernel == MRT_KERNEL_PACKET_DUAL) return coherent ? MRT_KERNEL_PACKET_DUAL : MRT_KERNEL_LANE;
+	if (ctx->opts.kernel == MRT_KERNEL_PACKET_DUAL || ctx->opts.kernel == MRT_KERNEL_PACKET_ROWS)
+		return !coherent ? MRT_KERNEL_LANE : (ctx->d_rows ? ctx->opts.kernel : MRT_KERNEL_PACKET_ASM);
 	if (ctx->opts.kernel >= MRT_KERNEL_LANE && ctx->opts.kernel <= MRT_KERNEL_LANE8_PERSISTENT) return ctx->opts.kernel;
-	// PACKET_ASM: same walk with the hand-written node loop (the compiler's loop is scalar-ALU bound)
-	return coherent ? MRT_KERNEL_PACKET_ASM : MRT_KERNEL_LANE;
+	if (!coherent) return MRT_KERNEL_LANE;
+	// Coherent batches: the 128-ray shared walk over the row array (packet_rows_kernel.h) once the batch is large
+	// enough to fill the chip with half as many waves (C3 2.16 -> 2.06 ms, C5 23.2 -> 21.2 ms; C2's 2^20 rays are
+	// 7 % faster with one packet per wave: 0.188 against 0.202 ms), else the 64-ray packet kernel with the
+	// hand-written node loop.
+	return (ctx->d_rows && count >= (1ull << 22)) ? MRT_KERNEL_PACKET_DUAL : MRT_KERNEL_PACKET_ASM;
+}
+
+// Flat scenes: the unified row array of the assembly packet walk, built on the device from the arrays just
+// uploaded / built.  Optional: a scene too large for its 26-bit row index, or a device short of memory, goes
+// without (coherent batches then take trace_packet_asm_kernel).
+int build_rows(mrt_ctx *ctx)
+{
+	const bool wanted = ctx->opts.kernel == MRT_KERNEL_AUTO || ctx->opts.kernel == MRT_KERNEL_PACKET_DUAL || ctx->opts.kernel == MRT_KERNEL_PACKET_ROWS;
+	const uint64_t n_rows = (uint64_t)ctx->n_nodes + ctx->n_tris;
+	if (!wanted || n_rows >= mrt::kAsmNodeLimit) return MRT_OK;
+	if (hipMalloc(&ctx->d_rows, (size_t)n_rows * 64u) != hipSuccess) { ctx->d_rows = nullptr; (void)hipGetLastError(); return MRT_OK; }
+	HIP_TRY(ctx, mrt::launch_build_rows(ctx->d_nodes, ctx->d_hot, ctx->d_cold, ctx->n_nodes, ctx->n_tris, ctx->d_rows, ctx->stream));
+	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	return MRT_OK;
 }
 
 int drain_pending(mrt_ctx *ctx)
@@ -275,7 +300,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	const uint32_t thr = ctx->opts.sort_threshold ? ctx->opts.sort_threshold : 256u; // MIN_BATCH_FOR_SORTING
 	const bool sort = !(flags & MRT_FLAG_COHERENT) && (count >= thr || (flags & MRT_FLAG_FORCE_SORT));
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
-	p.kernel = pick_kernel(ctx, !sort && (flags & MRT_FLAG_COHERENT));
+	p.kernel = pick_kernel(ctx, !sort && (flags & MRT_FLAG_COHERENT), count);
 	if (sort) {
 		const uint32_t *perm = nullptr;
 		if ((rc = device_sort(ctx, d_rays, p.in_fmt, count, &perm))) return rc;
@@ -345,6 +370,8 @@ int finish_timing(mrt_ctx *ctx, bool h2d, bool sorted, bool d2h)
 		ctx->stats.dead_pops += c[mrt::kCntDeadPops];
 		ctx->stats.wave_node_fetches += c[mrt::kCntWaveNodeFetch]; ctx->stats.wave_tri_fetches += c[mrt::kCntWaveTriFetch];
 		ctx->stats.leaf_box_checks += c[mrt::kCntLeafBoxChecks];
+		ctx->stats.fetch_wait_cycles += c[mrt::kCntFetchWaitCycles]; ctx->stats.wave_cycles += c[mrt::kCntWaveCycles];
+		ctx->stats.waves += c[mrt::kCntWaves];
 	}
 	return MRT_OK;
 }
@@ -451,7 +478,8 @@ const char *mrt_kernel_name(uint32_t kernel)
 		case MRT_KERNEL_LANE: return "trace_lane_kernel";
 		case MRT_KERNEL_PACKET: return "trace_packet_kernel";
 		case MRT_KERNEL_PACKET_ASM: return "trace_packet_asm_kernel";
-		case MRT_KERNEL_PACKET_DUAL: return "trace_packet_dual_kernel";
+		case MRT_KERNEL_PACKET_DUAL: return "trace_packet_rows_kernel<2>";
+		case MRT_KERNEL_PACKET_ROWS: return "trace_packet_rows_kernel<1>";
 		case MRT_KERNEL_LANE_PERSISTENT: return "trace_lane_persistent_kernel<2>";
 		case MRT_KERNEL_LANE4_PERSISTENT: return "trace_lane_persistent_kernel<4>";
 		case MRT_KERNEL_LANE8_PERSISTENT: return "trace_lane_persistent_kernel<8>";
@@ -470,7 +498,7 @@ int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
 	if (!out) return MRT_ERR_INVALID;
 	*out = nullptr;
 	if (opts && opts->struct_size != sizeof(mrt_options)) return MRT_ERR_INVALID;
-	if (opts && (opts->kernel > MRT_KERNEL_PACKET_DUAL || opts->kernel == 3u || opts->kernel == 4u)) return MRT_ERR_INVALID; // 3, 4: retired ids
+	if (opts && (opts->kernel > MRT_KERNEL_PACKET_ROWS || opts->kernel == 3u || opts->kernel == 4u)) return MRT_ERR_INVALID; // 3, 4: retired ids
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || device_ordinal < 0 || device_ordinal >= n) return MRT_ERR_NO_DEVICE;
 	mrt_ctx *ctx = new (std::nothrow) mrt_ctx();
@@ -574,6 +602,7 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	// LDS stack entries per lane: what this BVH can need, rounded up to 8, at most 64.
 	ctx->stack_depth = ((h.depth + 7u) / 8u) * 8u;
 	if (ctx->stack_depth < 8) ctx->stack_depth = 8;
+	if ((rc = build_rows(ctx))) { free_scene(ctx); return rc; }
 	ctx->scene = true;
 	return MRT_OK;
 }
@@ -634,6 +663,7 @@ int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	ctx->stack_depth = ((b.depth + 7u) / 8u) * 8u;
 	if (ctx->stack_depth < 8) ctx->stack_depth = 8;
 	ctx->stats.last_build_ms = ms;
+	if ((rc = build_rows(ctx))) { free_scene(ctx); return rc; }
 	ctx->scene = true;
 	return MRT_OK;
 }
@@ -971,7 +1001,7 @@ int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t
 	p.hits = d_hits; p.query_mask = query_mask;
 	p.out_fmt = out_format(flags, mode);
 	p.lane_map = ctx->opts.grid_tile == 1 ? mrt::MAP_LINEAR : mrt::MAP_TILE8X8;
-	p.kernel = pick_kernel(ctx, true);
+	p.kernel = pick_kernel(ctx, true, p.count);
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
@@ -1001,7 +1031,7 @@ int mrt_cast_tiled(mrt_ctx *ctx, const mrt_ray32 *d_rays, mrt_hit32 *d_hits,
 	p.rays = d_rays; p.hits = d_hits; p.count = (uint64_t)grid_w * rows; p.query_mask = query_mask;
 	p.in_fmt = mrt::IN_RAY32; p.out_fmt = mrt::OUT_HIT32;
 	p.lane_map = ctx->opts.grid_tile == 1 ? mrt::MAP_LINEAR : mrt::MAP_TILE8X8;
-	p.kernel = pick_kernel(ctx, true);
+	p.kernel = pick_kernel(ctx, true, p.count);
 	p.grid_w = grid_w; p.grid_h = rows; p.y0 = 0; p.rows = rows;
 	p.tiles_x = (grid_w + (1u << p.tile_w_log2) - 1u) >> p.tile_w_log2;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));

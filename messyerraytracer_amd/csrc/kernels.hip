@@ -352,8 +352,43 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 #include "lane_persistent_kernel.h"
 #include "packet_kernel.h"
 #include "packet_asm_kernel.h"
-#include "packet_dual_kernel.h"
+#include "packet_rows_kernel.h"
 #include "two_level_kernel.h"
+
+// ---- the unified row array of packet_rows_kernel.h ------------------------------------------------------------
+// rows[0, n_nodes) = the wide nodes with leaf refs rebased to row indices (0x80000000 | (n_nodes + first slot));
+// rows[n_nodes + s] = triangle slot s as {v0,id | e1,layers | e2,flags | normal}: the hot and the cold row of the
+// triangle in one 64-byte line, which is the reference's GPUTrianglePacked row (src/api/gpu_types.h:44-51).
+__global__ __launch_bounds__(MRT_WG) void build_rows_kernel(const DevNode *nodes, const TriHot *hot, const TriCold *cold,
+		uint32_t n_nodes, uint32_t n_tris, float4 *rows)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * MRT_WG + threadIdx.x;
+	if (g >= (uint64_t)n_nodes + n_tris) return;
+	float4 *out = rows + g * 4u;
+	if (g < n_nodes) {
+		const float4 *n = reinterpret_cast<const float4 *>(nodes) + g * 4u;
+		float4 a = n[0], b = n[1];
+		uint32_t l = __float_as_uint(a.w), r = __float_as_uint(b.w);
+		if (l >= kLeafBit) l = kLeafBit | (n_nodes + (l & 0x7FFFFFFFu));
+		if (r >= kLeafBit) r = kLeafBit | (n_nodes + (r & 0x7FFFFFFFu));
+		a.w = __uint_as_float(l); b.w = __uint_as_float(r);
+		out[0] = a; out[1] = b; out[2] = n[2]; out[3] = n[3];
+	} else {
+		const uint64_t s = g - n_nodes;
+		const float4 *t = reinterpret_cast<const float4 *>(hot) + s * 3u;
+		out[0] = t[0]; out[1] = t[1]; out[2] = t[2];
+		out[3] = reinterpret_cast<const float4 *>(cold)[s];
+	}
+}
+
+hipError_t launch_build_rows(const DevNode *nodes, const TriHot *hot, const TriCold *cold, uint32_t n_nodes, uint32_t n_tris,
+		void *rows, hipStream_t stream)
+{
+	const uint64_t total = (uint64_t)n_nodes + n_tris;
+	hipLaunchKernelGGL(build_rows_kernel, dim3((uint32_t)((total + MRT_WG - 1) / MRT_WG)), dim3(MRT_WG), 0, stream,
+			nodes, hot, cold, n_nodes, n_tris, reinterpret_cast<float4 *>(rows));
+	return hipGetLastError();
+}
 
 // ---- standalone ray generation (mrt_generate_grid) ---------------------------------
 __global__ __launch_bounds__(MRT_WG) void grid_rays_kernel(const TraceParams p, mrt_ray32 *out)
@@ -606,18 +641,24 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		else hipLaunchKernelGGL((trace_two_level_kernel<false>), grid, wg, lds2, stream, p);
 		return hipGetLastError();
 	}
-	if (p.kernel == MRT_KERNEL_PACKET_DUAL) { // two packets per wave: half the waves
-		const uint64_t dblocks = (threads + 2u * MRT_WG - 1) / (2u * MRT_WG);
-		dim3 dgrid((uint32_t)dblocks);
-		if (count) {
-			if (any_hit) hipLaunchKernelGGL((trace_packet_dual_kernel<true, true>), dgrid, wg, p.extra_lds, stream, p);
-			else hipLaunchKernelGGL((trace_packet_dual_kernel<false, true>), dgrid, wg, p.extra_lds, stream, p);
-		} else if (any_hit) hipLaunchKernelGGL((trace_packet_dual_kernel<true>), dgrid, wg, p.extra_lds, stream, p);
-		else hipLaunchKernelGGL((trace_packet_dual_kernel<false>), dgrid, wg, p.extra_lds, stream, p);
+	if ((p.kernel == MRT_KERNEL_PACKET_DUAL || p.kernel == MRT_KERNEL_PACKET_ROWS) && p.row_array != nullptr) {
+		// the walk over the unified row array: one or two packets per wave (two: half the waves)
+		const uint32_t packets = p.kernel == MRT_KERNEL_PACKET_DUAL ? 2u : 1u;
+		const uint64_t rblocks = (threads + packets * MRT_WG - 1) / (packets * MRT_WG);
+		dim3 rgrid((uint32_t)rblocks);
+#define MRT_LAUNCH_ROWS(A, C, N) hipLaunchKernelGGL((trace_packet_rows_kernel<A, C, N>), rgrid, wg, p.extra_lds, stream, p)
+		if (packets == 2u) {
+			if (count) { if (any_hit) MRT_LAUNCH_ROWS(true, true, 2); else MRT_LAUNCH_ROWS(false, true, 2); }
+			else { if (any_hit) MRT_LAUNCH_ROWS(true, false, 2); else MRT_LAUNCH_ROWS(false, false, 2); }
+		} else {
+			if (count) { if (any_hit) MRT_LAUNCH_ROWS(true, true, 1); else MRT_LAUNCH_ROWS(false, true, 1); }
+			else { if (any_hit) MRT_LAUNCH_ROWS(true, false, 1); else MRT_LAUNCH_ROWS(false, false, 1); }
+		}
+#undef MRT_LAUNCH_ROWS
 		return hipGetLastError();
 	}
 	// scenes whose node offsets pass the asm loop's 32 bits use the C++ packet kernel
-	if (p.kernel == MRT_KERNEL_PACKET_ASM && p.n_nodes < kAsmNodeLimit) {
+	if ((p.kernel == MRT_KERNEL_PACKET_ASM || p.kernel == MRT_KERNEL_PACKET_DUAL || p.kernel == MRT_KERNEL_PACKET_ROWS) && p.n_nodes < kAsmNodeLimit) {
 		if (count) {
 			if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true, true>), grid, wg, p.extra_lds, stream, p);
 			else hipLaunchKernelGGL((trace_packet_asm_kernel<false, true>), grid, wg, p.extra_lds, stream, p);
@@ -625,7 +666,7 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		else hipLaunchKernelGGL((trace_packet_asm_kernel<false>), grid, wg, p.extra_lds, stream, p);
 		return hipGetLastError();
 	}
-	if (p.kernel == MRT_KERNEL_PACKET || p.kernel == MRT_KERNEL_PACKET_ASM) {
+	if (p.kernel == MRT_KERNEL_PACKET || p.kernel == MRT_KERNEL_PACKET_ASM || p.kernel == MRT_KERNEL_PACKET_DUAL || p.kernel == MRT_KERNEL_PACKET_ROWS) {
 		if (any_hit) {
 			if (count) hipLaunchKernelGGL((trace_packet_kernel<true, true>), grid, wg, 0, stream, p);
 			else hipLaunchKernelGGL((trace_packet_kernel<true, false>), grid, wg, 0, stream, p);

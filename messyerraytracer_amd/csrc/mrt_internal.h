@@ -82,6 +82,7 @@ constexpr int kCntWaveNodeFetch = 6; // node fetches as the hardware sees them: 
                                      // = one divergent 64-/128-byte line (lane kernels)
 constexpr int kCntWaveTriFetch = 7;  // triangle rows fetched: one per wave step (packet kernels), one per lane test (lane kernels)
 constexpr int kCntLeafBoxChecks = 8; // 8-wide kernel: exact leaf boxes read for candidate hits
+constexpr int kCntFetchWaitCycles = 9, kCntWaveCycles = 10, kCntWaves = 11; // trace_packet_rows_kernel<.., 1>: s_memtime clock
 constexpr int kNumCounters = 16;
 constexpr int kAutoGridOff = kNumCounters;         // 8 words: what detect_grid_kernel found (4 x u32 used)
 constexpr int kDetectScratchOff = kAutoGridOff + 8; // 1026 words: jump masks + ticket + wide-neighbour count
@@ -107,6 +108,7 @@ struct TraceParams {
 	const DevInstance *instances; // two-level scenes (kernel == MRT_KERNEL_TWO_LEVEL)
 	const TriHot *tri_hot;
 	const TriCold *tri_cold;
+	const void *row_array;     // nodes + triangles as one array of 64-byte rows (packet_rows_kernel.h; may be null)
 	const void *rays;          // IN_RAY32 / IN_HOST60 (device)
 	void *hits;                // device
 	const uint32_t *perm;      // optional: lane g traces ray perm[g], writes hits[perm[g]]
@@ -126,6 +128,7 @@ struct TraceParams {
 	uint32_t xcd_swizzle;      // 1: remap blockIdx so each XCD owns a contiguous band
 	uint32_t n_tris;           // rows in tri_hot / tri_cold (token validation)
 	uint32_t n_nodes;          // rows in nodes (the hand-written node loop addresses them with a 32-bit byte offset)
+	uint32_t count_mode;       // COUNT variants: mrt_options.count_visits (1: visit counters, 2: only the sampled clock of the rows kernel)
 	uint32_t extra_lds;        // experiments: dynamic LDS bytes added per workgroup of the packet kernels (occupancy sweeps)
 	mrt_camera cam;
 };

@@ -31,8 +31,7 @@
 //   s44..s46 rmin.xyz  s47 -        | s48..s50 rmax.xyz  s51 -
 // scratch: s52 byte offset, s53 far ref, s[54:55] right-child mask, s[56:57] "left is nearer" flags,
 // s[58:59] mask of the pushed (far) child, s[60:61] mask of the entered child, v50..v55 slab values (one box
-// at a time: six temporaries; the same registers as the two-packet loop of packet_dual_kernel.h, which hands
-// its last packet over to this one), v58 the never-read destination of the far-child prefetch.
+// at a time: six temporaries), v58 the never-read destination of the far-child prefetch.
 //
 // Stack entries are 16 bytes: {ref, -, lane mask (64 bit)}.  The mask holds the lanes whose OWN ray hit the
 // box of the pushed child; it matters only when that child is a leaf (packet_kernel.h: a lane accepts
@@ -196,10 +195,8 @@ __device__ __forceinline__ void packet_traverse_asm(const TraceParams &p, const 
 		float &best_t, float &best_u, float &best_v, uint32_t &best_slot,
 		uint32_t &n_nodes, uint32_t &n_tris, // COUNT: wave-uniform numbers of node steps and triangle rows fetched
 		// a BLAS of a two-level scene (two_level_kernel.h): its root, the instance's flat id base, the id of the
-		// best hit so far (in / out), and whether this lane sits the walk out (its world ray missed the instance).
-		// A walk taken over from the two-packet loop (packet_dual_kernel.h) starts at `root` = the node it stands
-		// at, or with a pop (dopop0 = 1).
-		uint32_t root = 0u, uint32_t id_base = 0u, uint32_t *best_id_io = nullptr, bool dead = false, uint32_t dopop0 = 0u)
+		// best hit so far (in / out), and whether this lane sits the walk out (its world ray missed the instance)
+		uint32_t root = 0u, uint32_t id_base = 0u, uint32_t *best_id_io = nullptr, bool dead = false)
 {
 	const bool degenerate = r.t_min >= r.t_max;
 	float lim_t = (degenerate || dead) ? -FLT_MAX : best_t;
@@ -208,7 +205,7 @@ __device__ __forceinline__ void packet_traverse_asm(const TraceParams &p, const 
 	const float4 *hot = reinterpret_cast<const float4 *>(p.tri_hot);
 	uint32_t best_id = best_id_io ? *best_id_io : 0xFFFFFFFFu;
 	uint32_t cur = root; // always a wide node
-	uint32_t dopop = dopop0;
+	uint32_t dopop = 0;
 	uint32_t steps = 0;  // COUNT: node steps of this walk (an SGPR inside the asm block)
 	for (;;) {
 		packet_node_loop_asm<OCT, COUNT>(p.nodes, cur, sp, dopop, steps, ix, iy, iz, nrx, nry, nrz, r.t_min, lim_t);

@@ -57,7 +57,7 @@ def test_null_arguments_are_rejected_not_crashed(built):
     assert L.mrt_update_instances(None, None, 0) == capi.ERR_INVALID
     assert L.mrt_expand_grid_tokens(None, None, 0, 0, 0, 0, None, None, None) == capi.ERR_INVALID
     assert L.mrt_camera_perspective(None, None, None, 0, 0, 0.0) == capi.ERR_INVALID
-    assert L.mrt_kernel_name(capi.KERNEL_PACKET_DUAL) == b"trace_packet_dual_kernel" and L.mrt_kernel_name(77) == b"?"
+    assert L.mrt_kernel_name(capi.KERNEL_PACKET_DUAL) == b"trace_packet_rows_kernel<2>" and L.mrt_kernel_name(77) == b"?"
     L.mrt_destroy(None)  # no-op
 
 

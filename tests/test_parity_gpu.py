@@ -355,7 +355,7 @@ def test_row_width_detection_for_coherent_batches(built):
 
 
 @pytest.mark.parametrize("kernel", [capi.KERNEL_LANE, capi.KERNEL_PACKET,
-                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
+                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
                                     capi.KERNEL_LANE8_PERSISTENT])
 def test_both_kernels_on_every_kind_of_batch(built, kernel):
     """Either kernel must give the oracle's answer for any batch, coherent or not:
@@ -424,7 +424,7 @@ def test_async_flag_queues_casts_back_to_back(ctx, soup1k):
 
 
 @pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET,
-                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
+                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
                                     capi.KERNEL_LANE8_PERSISTENT])
 def test_hit_tokens_expand_to_identical_records(built, kernel):
     """MRT_FLAG_TOKEN_OUT + mrt_expand_tokens == the records of a plain cast, byte for byte
@@ -686,7 +686,7 @@ def _tiled_wall(n=12, pitch=1.0):
 
 
 @pytest.mark.parametrize("pitch", [1.0, 0.3, 0.7])
-@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL,
+@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS,
                                     capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT, capi.KERNEL_LANE8_PERSISTENT])
 def test_rays_that_graze_box_faces(built, kernel, pitch):
     """Axis-parallel rays whose origins lie exactly on tile edges: the ray runs IN a face plane of leaf and
@@ -728,7 +728,7 @@ def test_rays_that_graze_box_faces(built, kernel, pitch):
     c.close()
 
 
-@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL,
+@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS,
                                     capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT, capi.KERNEL_LANE8_PERSISTENT])
 def test_non_finite_rays_do_not_disturb_their_neighbours(built, kernel):
     """The reference only asserts ray validity in debug builds (RT_ASSERT_VALID_RAY); a release caller can hand

@@ -45,6 +45,8 @@ VARIANTS = {
     "asm_fused_zorder_swz": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_order=2, xcd_swizzle=1), "fused"),
     "asm_fused_swz": (dict(kernel=capi.KERNEL_PACKET_ASM, xcd_swizzle=1), "fused"),
     "asm_fused_16x4": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_w_log2=4), "fused"),
+    "rows1_fused": (dict(kernel=capi.KERNEL_PACKET_ROWS), "fused"),
+    "rows1_cast": (dict(kernel=capi.KERNEL_PACKET_ROWS), "cast"),
     "dual_fused": (dict(kernel=capi.KERNEL_PACKET_DUAL), "fused"),
     "dual_cast": (dict(kernel=capi.KERNEL_PACKET_DUAL), "cast"),
     "dual_fused_zorder": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=2), "fused"),
