@@ -411,6 +411,31 @@ int mrt_device_free(mrt_ctx *ctx, void *d_ptr);
 int mrt_memcpy_h2d(mrt_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int mrt_memcpy_d2h(mrt_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
 
+/* ---- several devices of one node from ONE process (no reference counterpart: the reference is
+ * single-device, and its callers — RayDispatcher, src/dispatch/ray_dispatcher.h:124-181; RayTracerServer, src/godot/
+ * raytracer_server.cpp:285-328 — are C++, which the torch.distributed path of bench.py cannot serve).  A group holds one
+ * context and one stream per member; the scene is replicated; a grid's rows are split into contiguous blocks
+ * (mrt_group_row_block), every member traces its block with rays generated in the kernel, 4-byte hit tokens travel to
+ * member 0 as peer copies (xGMI, each peer over its own link) and member 0 rebuilds the records, bit-identical to a
+ * single-device cast of the whole grid.  device_ordinals: n_devices HIP ordinals, NULL = 0 .. n_devices-1; an ordinal
+ * may repeat (several members on one device: how the multi-member path is exercised on a one-GPU box).
+ * Externally serialised like a context. */
+typedef struct mrt_group mrt_group;
+int mrt_group_create(int n_devices, const int *device_ordinals, const mrt_options *opts, mrt_group **out);
+void mrt_group_destroy(mrt_group *group);
+int mrt_group_size(const mrt_group *group);
+mrt_ctx *mrt_group_context(mrt_group *group, int member);   /* e.g. for mrt_get_stats of one member */
+const char *mrt_group_last_error(const mrt_group *group);
+void mrt_group_row_block(uint32_t member, uint32_t n_members, uint32_t rows, uint32_t *y0, uint32_t *y1);
+int mrt_group_upload_scene(mrt_group *group, const mrt_tri64 *tris, uint32_t n_tris,
+		const mrt_bvh_node32 *nodes, uint32_t used_nodes, const uint32_t *prim_idx);
+int mrt_group_upload_two_level_scene(mrt_group *group, const float *verts9, uint32_t n_mesh_tris,
+		const mrt_instance *instances, uint32_t n_instances, uint32_t flags);
+/* hits: grid_w * grid_h records row-major (mrt_hit32; uint8 with MRT_FLAG_BOOL_OUT in any-hit mode), on the host, or in
+ * member 0's device memory with MRT_FLAG_HITS_ON_DEVICE (the only other flag accepted).  Blocking. */
+int mrt_group_cast_grid(mrt_group *group, const mrt_camera *cam, uint32_t grid_w, uint32_t grid_h, void *hits,
+		uint32_t query_mask, int mode, uint32_t flags);
+
 #ifdef __cplusplus
 }
 #endif

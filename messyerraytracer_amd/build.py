@@ -8,11 +8,12 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmrt_hip.so")
 HOST_TEST = os.path.join(HERE, "host_mirror_test")
+HOST_CPU_TEST = os.path.join(HERE, "host_cpu_test")
 
-SOURCES = ["kernels.hip", "api.hip", "device_build.hip", "host/scene_prep.cpp", "host/bvh_builder.cpp",
+SOURCES = ["kernels.hip", "api.hip", "group.hip", "device_build.hip", "host/scene_prep.cpp", "host/bvh_builder.cpp",
            "host/two_level_prep.cpp"]
 HEADERS = ["mrt_internal.h", "packet_kernel.h", "packet_asm_kernel.h", "packet_rows_kernel.h", "two_level_kernel.h", "lane_persistent_kernel.h", "../../include/mrt_hip.h", "host/gpu_ray_caster.hpp", "host/ray_dispatcher.hpp",
-           "host/host_types.hpp"]
+           "host/host_types.hpp", "host/cpu_backend.hpp", "host/ray_tracer_server.hpp"]
 # -Xarch_host -mfma: explicit fmaf() calls of the host code (the 8-wide collapse verifies every quantised
 # box with the kernel's own fma) become one instruction instead of a libm call; nothing is contracted
 # implicitly (-ffp-contract=off), so every result is unchanged.
@@ -60,6 +61,20 @@ def build_host_test(force: bool = False) -> str:
     return HOST_TEST
 
 
+def build_host_cpu_test(force: bool = False) -> str:
+    """C++ test driver for the RayTracerServer mirror over the router's CPU backend (links the C-ABI for the host-side builder)."""
+    src = os.path.join(CSRC, "host", "host_cpu_test.cpp")
+    deps = [src, LIB] + [os.path.join(CSRC, h) for h in HEADERS]
+    if force or _stale(HOST_CPU_TEST, deps):
+        cmd = [_hipcc(), "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", src, "-o", HOST_CPU_TEST,
+               "-L" + HERE, "-lmrt_hip", "-Wl,-rpath," + HERE, "-pthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+        if r.returncode != 0:
+            raise RuntimeError("host cpu test build failed:\n" + r.stdout + r.stderr)
+    return HOST_CPU_TEST
+
+
 if __name__ == "__main__":
     print(build_lib(force=True, verbose=True))
     print(build_host_test(force=True))
+    print(build_host_cpu_test(force=True))

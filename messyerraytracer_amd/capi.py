@@ -32,6 +32,8 @@ SYMBOLS = [
     "mrt_camera_look", "mrt_camera_perspective", "mrt_camera_orthographic", "mrt_generate_grid", "mrt_cast_grid", "mrt_cast_tiled", "mrt_expand_tokens",
     "mrt_expand_grid_tokens", "mrt_morton_keys",
     "mrt_kernel_name", "mrt_struct_size", "mrt_get_stats", "mrt_device_alloc", "mrt_device_free", "mrt_memcpy_h2d", "mrt_memcpy_d2h",
+    "mrt_group_create", "mrt_group_destroy", "mrt_group_size", "mrt_group_context", "mrt_group_last_error", "mrt_group_row_block",
+    "mrt_group_upload_scene", "mrt_group_upload_two_level_scene", "mrt_group_cast_grid",
 ]
 
 
@@ -124,6 +126,19 @@ def load():
     L.mrt_device_free.argtypes = [C.c_void_p, C.c_void_p]
     L.mrt_memcpy_h2d.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
     L.mrt_memcpy_d2h.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.mrt_group_create.argtypes = [C.c_int, C.POINTER(C.c_int), C.POINTER(Options), C.POINTER(C.c_void_p)]
+    L.mrt_group_destroy.argtypes = [C.c_void_p]
+    L.mrt_group_destroy.restype = None
+    L.mrt_group_size.argtypes = [C.c_void_p]
+    L.mrt_group_context.argtypes = [C.c_void_p, C.c_int]
+    L.mrt_group_context.restype = C.c_void_p
+    L.mrt_group_last_error.argtypes = [C.c_void_p]
+    L.mrt_group_last_error.restype = C.c_char_p
+    L.mrt_group_row_block.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.mrt_group_row_block.restype = None
+    L.mrt_group_upload_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p]
+    L.mrt_group_upload_two_level_scene.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_uint32]
+    L.mrt_group_cast_grid.argtypes = [C.c_void_p, C.POINTER(Camera), C.c_uint32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int, C.c_uint32]
     _lib = L
     return L
 
@@ -412,6 +427,62 @@ class Context:
 
     def d2h(self, arr: np.ndarray, d_ptr: int):
         self._chk(self.L.mrt_memcpy_d2h(self.h, _np(arr), C.c_void_p(d_ptr), arr.nbytes))
+
+
+class Group:
+    """mrt_group wrapper: several devices of one node driven from this process (rows of a grid sharded over them)."""
+
+    def __init__(self, devices, **opts_kw):
+        self.L = load()
+        opts = Options()
+        opts.struct_size = C.sizeof(Options)
+        for k, v in opts_kw.items():
+            setattr(opts, k, v)
+        devs = (C.c_int * len(devices))(*devices)
+        self.h = C.c_void_p()
+        rc = self.L.mrt_group_create(len(devices), devs, C.byref(opts), C.byref(self.h))
+        if rc:
+            raise MrtError(rc, self.L.mrt_status_string(rc).decode())
+
+    def _chk(self, rc):
+        if rc:
+            raise MrtError(rc, self.L.mrt_group_last_error(self.h).decode() or self.L.mrt_status_string(rc).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.mrt_group_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def size(self) -> int:
+        return self.L.mrt_group_size(self.h)
+
+    def upload(self, scene: "Scene"):
+        tris, nodes, prim_idx = np.ascontiguousarray(scene.tris), np.ascontiguousarray(scene.nodes), np.ascontiguousarray(scene.prim_idx, dtype=np.uint32)
+        self._chk(self.L.mrt_group_upload_scene(self.h, _np(tris), tris.shape[0], _np(nodes), nodes.shape[0], _np(prim_idx)))
+
+    def upload_two_level_scene(self, verts9, instances, blas_on_device=False):
+        verts9 = np.ascontiguousarray(verts9, dtype=np.float32)
+        instances = np.ascontiguousarray(instances)
+        self._chk(self.L.mrt_group_upload_two_level_scene(self.h, _np(verts9), verts9.size // 9, _np(instances), instances.shape[0],
+                                                          BUILD_BLAS_ON_DEVICE if blas_on_device else 0))
+
+    def cast_grid(self, cam, grid_w, grid_h, hits=None, query_mask=0xFFFFFFFF, mode=MODE_NEAREST, flags=0):
+        if hits is None:
+            hits = np.zeros(grid_w * grid_h, dtype=np.uint8 if (flags & FLAG_BOOL_OUT) else T.HIT32)
+        self._chk(self.L.mrt_group_cast_grid(self.h, C.byref(cam), grid_w, grid_h, _ptr(hits), query_mask, mode, flags))
+        return hits
+
+
+def group_row_block(member: int, n_members: int, rows: int):
+    y0, y1 = C.c_uint32(), C.c_uint32()
+    load().mrt_group_row_block(member, n_members, rows, C.byref(y0), C.byref(y1))
+    return y0.value, y1.value
 
 
 class Scene:

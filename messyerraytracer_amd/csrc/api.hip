@@ -31,7 +31,7 @@ hipError_t launch_flatten_instances(const float *d_verts9, const mrt_instance *d
 		uint32_t n_instances, uint32_t max_tris_per_instance, mrt_tri64 *d_out, void *stream);
 hipError_t launch_morton_keys(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t *keys, uint32_t *index, hipStream_t stream);
 hipError_t launch_trace_persistent(const TraceParams &p, unsigned long long *next_ray, uint32_t *overflow,
-		uint32_t lds_depth, uint32_t refill, uint32_t leaf_wait, uint32_t blocks, bool any_hit, hipStream_t stream);
+		uint32_t lds_depth, uint32_t refill, uint32_t leaf_wait, uint32_t blocks, bool any_hit, bool count, hipStream_t stream);
 hipError_t launch_origin_dir_keys(const void *rays, uint32_t in_fmt, uint64_t count, const float lo[3], const float hi[3],
 		uint32_t *keys, uint32_t *index, hipStream_t stream);
 hipError_t launch_detect_grid(const void *rays, uint32_t in_fmt, uint64_t count, uint32_t tile_w_log2,
@@ -236,8 +236,10 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 			(ctx->opts.kernel == MRT_KERNEL_AUTO && persistent));
 	const bool wide8 = ctx->d_nodes8 != nullptr && (ctx->opts.kernel == MRT_KERNEL_LANE8_PERSISTENT ||
 			(ctx->opts.kernel == MRT_KERNEL_AUTO && persistent));
-	if ((wide4 || wide8) && !ctx->opts.count_visits) persistent = true;
-	if (!persistent || ctx->opts.count_visits) {
+	// counting builds: the persistent kernels count for flat scenes; two-level scenes take the plain lane kernel
+	const bool can_count = !ctx->opts.count_visits || !ctx->two_level;
+	if ((wide4 || wide8) && can_count) persistent = true;
+	if (!persistent || !can_count) {
 		p.kernel = ctx->two_level ? mrt::MRT_KERNEL_TWO_LEVEL : MRT_KERNEL_LANE;
 		HIP_TRY(ctx, mrt::launch_trace(p, any_hit, ctx->opts.count_visits != 0, ctx->stream));
 		ctx->queued_kernel = p.kernel;
@@ -261,7 +263,8 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 	unsigned long long *next_ray = ctx->d_counters + mrt::kNextRayOff;
 	HIP_TRY(ctx, hipMemsetAsync(next_ray, 0, 128 * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace_persistent(p, next_ray, ovf, lds_depth, ctx->opts.refill ? ctx->opts.refill : 16u,
-			ctx->opts.leaf_wait ? ctx->opts.leaf_wait : (wide8 ? 8u : 16u), (uint32_t)blocks, any_hit, ctx->stream));
+			ctx->opts.leaf_wait ? ctx->opts.leaf_wait : (wide8 ? 8u : 16u), (uint32_t)blocks, any_hit,
+			ctx->opts.count_visits != 0 && !ctx->two_level, ctx->stream));
 	ctx->queued_kernel = p.kernel;
 	return MRT_OK;
 }
@@ -334,7 +337,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 		ctx->queued_kernel = packet_kernel;
 	} else {
 		// large incoherent batches: resident waves that pull rays from a counter (no counting variant)
-		const bool persistent = !ctx->opts.count_visits && p.lane_map == mrt::MAP_LINEAR &&
+		const bool persistent = p.lane_map == mrt::MAP_LINEAR &&
 				(persistent_kind || (ctx->opts.kernel == MRT_KERNEL_AUTO && count >= 65536 &&
 					(p.kernel == MRT_KERNEL_LANE || p.kernel == mrt::MRT_KERNEL_TWO_LEVEL)));
 		if (persistent_kind || p.kernel == MRT_KERNEL_LANE || p.kernel == mrt::MRT_KERNEL_TWO_LEVEL) {

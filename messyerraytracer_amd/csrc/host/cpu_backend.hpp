@@ -1,0 +1,215 @@
+// cpu_backend.hpp — the CPU half of RayDispatcher (src/dispatch/ray_dispatcher.h:152-180,214-240,443-463) and the
+// ThreadPool it splits batches over (src/dispatch/thread_pool.h:77-133,173-222), for the host-side mirror.
+//
+// In the reference the CPU path is TinyBVH (BVH4 / BVH8 SIMD walks) behind RayScene::cast_rays.  TinyBVH is the
+// reference's vendored dependency and stays with the reference; what a host needs from this repository is a router
+// that still answers when the caller selects Backend::CPU (BASELINE.json config 1 is "cast_debug_rays on the CPU
+// ThreadPool backend").  This walk goes over the SAME arrays the device is fed — the 8-bin SAH BVH2 that
+// mrt_bvh2_build makes, the reference's Triangle PODs — with the acceptance rules and the operation order of the
+// device kernels ("Arithmetic": explicit fma, slab test of bvh_traverse.comp.glsl:84-99, Moller-Trumbore
+// of :105-131, an exact tie to the lower triangle id), so the two backends of one router return the same records bit
+// for bit.  It is an explicit backend, never a fallback: Backend::GPU and Backend::AUTO do not degrade to it
+// (ray_dispatcher.hpp), and libmrt_hip.so itself has no CPU path at all.
+//
+// Compile with -ffp-contract=off (as everything here): the fused operations are the explicit std::fmaf calls.
+#pragma once
+#include <algorithm>
+#include <atomic>
+#include <cfloat>
+#include <cmath>
+#include <condition_variable>
+#include <cstdint>
+#include <functional>
+#include <mutex>
+#include <thread>
+#include <vector>
+#include "host_types.hpp"
+#include "../../../include/mrt_hip.h"
+
+namespace mrt {
+
+// ThreadPool::dispatch_and_wait, thread_pool.h:77-133: chunks = workers + 1, chunk = ceil(count / chunks), the caller
+// runs chunk 0, the workers grab the rest from an atomic counter, a condition variable ends the wait.
+class ThreadPool {
+public:
+	explicit ThreadPool(uint32_t threads = 0) // thread_pool.h:35-57: hardware_concurrency - 1 workers
+	{
+		uint32_t hw = std::thread::hardware_concurrency();
+		thread_count_ = threads ? threads : (hw > 1 ? hw - 1 : 0);
+		for (uint32_t i = 0; i < thread_count_; i++) workers_.emplace_back([this] { worker_loop(); });
+	}
+	~ThreadPool()
+	{
+		{ std::lock_guard<std::mutex> lock(mutex_); shutdown_ = true; }
+		cv_work_.notify_all();
+		for (auto &t : workers_) if (t.joinable()) t.join();
+	}
+	ThreadPool(const ThreadPool &) = delete;
+	ThreadPool &operator=(const ThreadPool &) = delete;
+
+	void dispatch_and_wait(int count, int min_batch_size, const std::function<void(int, int)> &func)
+	{
+		if (count <= 0) return;
+		if (count <= min_batch_size || thread_count_ == 0) { func(0, count); return; }
+		const uint32_t num_chunks = thread_count_ + 1;
+		const int chunk_size = (int)(((uint32_t)count + num_chunks - 1) / num_chunks);
+		{
+			std::lock_guard<std::mutex> lock(mutex_);
+			work_func_ = &func; work_chunk_size_ = chunk_size; work_total_ = count;
+			work_next_chunk_.store(1);          // chunk 0 is the calling thread's
+			pending_workers_ = thread_count_;   // every worker reports once per generation
+			work_generation_++;
+		}
+		cv_work_.notify_all();
+		func(0, std::min(chunk_size, count));
+		std::unique_lock<std::mutex> lock(mutex_);
+		cv_done_.wait(lock, [this] { return pending_workers_ == 0; });
+	}
+	uint32_t thread_count() const { return thread_count_; }
+
+private:
+	std::vector<std::thread> workers_;
+	uint32_t thread_count_ = 0;
+	std::mutex mutex_;
+	std::condition_variable cv_work_, cv_done_;
+	bool shutdown_ = false;
+	const std::function<void(int, int)> *work_func_ = nullptr;
+	int work_chunk_size_ = 0, work_total_ = 0;
+	std::atomic<uint32_t> work_next_chunk_{0};
+	uint32_t pending_workers_ = 0;
+	uint64_t work_generation_ = 0;
+
+	void worker_loop()
+	{
+		uint64_t last_gen = 0;
+		for (;;) {
+			const std::function<void(int, int)> *func; int chunk_size, total;
+			{
+				std::unique_lock<std::mutex> lock(mutex_);
+				cv_work_.wait(lock, [this, last_gen] { return shutdown_ || work_generation_ > last_gen; });
+				if (shutdown_) return;
+				last_gen = work_generation_;
+				func = work_func_; chunk_size = work_chunk_size_; total = work_total_;
+			}
+			for (;;) {
+				const uint32_t chunk = work_next_chunk_.fetch_add(1);
+				const long long start = (long long)chunk * chunk_size;
+				if (start >= total) break;
+				(*func)((int)start, (int)std::min<long long>(start + chunk_size, total));
+			}
+			std::lock_guard<std::mutex> lock(mutex_);
+			if (--pending_workers_ == 0) cv_done_.notify_one();
+		}
+	}
+};
+
+// One ray against the scene's BVH2 (TinyBVH node layout: leftFirst = left child / first prim, triCount > 0 = leaf;
+// children are adjacent; node 1 is unused).  RayScene::cast_ray / any_hit (src/accel/ray_scene.h:90-118,136-163) with
+// the device kernels' arithmetic.
+class CpuWalker {
+public:
+	CpuWalker(const Triangle *tris, const mrt_bvh_node32 *nodes, const uint32_t *prim_idx, uint32_t n_tris)
+		: tris_(tris), nodes_(nodes), prim_idx_(prim_idx), n_tris_(n_tris) {}
+
+	// closest hit (any_hit = false) or first hit found (any_hit = true); stats may be null
+	Intersection cast(const Ray &ray, uint32_t query_mask, bool any_hit, RayStats *stats) const
+	{
+		Intersection out; // a miss record as the default constructor leaves it (Intersection::set_miss, intersection.h:45-52)
+		if (stats) stats->rays_cast++;
+		if (n_tris_ == 0 || ray.t_min >= ray.t_max) return out; // degenerate rays are misses (glsl:214-222)
+		const float ox = ray.origin.x, oy = ray.origin.y, oz = ray.origin.z;
+		const float dx = ray.direction.x, dy = ray.direction.y, dz = ray.direction.z;
+		const float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
+		const float nrx = -(ox * ix), nry = -(oy * iy), nrz = -(oz * iz);
+		float best_t = ray.t_max, best_u = 0.0f, best_v = 0.0f;
+		uint32_t best_tri = UINT32_MAX, best_id = UINT32_MAX;
+		uint32_t stack[128];
+		int sp = 0;
+		uint32_t cur = 0;
+		// The root's own box is not tested (the device's wide root holds its children's boxes) -- except when the root is
+		// a leaf: upload_scene wraps it as the left child of a wide root (gpu_ray_caster.cpp:255-271), box test included.
+		if (nodes_[0].tri_count > 0) {
+			float tn;
+			if (stats) stats->bvh_nodes_visited++;
+			if (!slab(nodes_[0], ix, iy, iz, nrx, nry, nrz, ray.t_min, best_t, tn)) return out;
+		}
+		for (;;) {
+			const mrt_bvh_node32 &n = nodes_[cur];
+			if (n.tri_count > 0) {
+				for (uint32_t k = 0; k < n.tri_count; k++) {
+					const uint32_t ti = prim_idx_[n.left_first + k];
+					const Triangle &t = tris_[ti];
+					if ((t.layers & query_mask) == 0u) continue;
+					if (stats) stats->tri_tests++;
+					// ray_triangle, glsl:105-131 == Triangle::intersect, src/core/triangle.h:56-105
+					const float pvx = std::fmaf(dy, t.edge2.z, -(dz * t.edge2.y));
+					const float pvy = std::fmaf(dz, t.edge2.x, -(dx * t.edge2.z));
+					const float pvz = std::fmaf(dx, t.edge2.y, -(dy * t.edge2.x));
+					const float det = dot3(t.edge1.x, t.edge1.y, t.edge1.z, pvx, pvy, pvz);
+					if (std::fabs(det) < 1e-8f) continue;
+					const float inv_det = 1.0f / det;
+					const float tvx = ox - t.v0.x, tvy = oy - t.v0.y, tvz = oz - t.v0.z;
+					const float u = dot3(tvx, tvy, tvz, pvx, pvy, pvz) * inv_det;
+					if (u < 0.0f || u > 1.0f) continue;
+					const float qvx = std::fmaf(tvy, t.edge1.z, -(tvz * t.edge1.y));
+					const float qvy = std::fmaf(tvz, t.edge1.x, -(tvx * t.edge1.z));
+					const float qvz = std::fmaf(tvx, t.edge1.y, -(tvy * t.edge1.x));
+					const float v = dot3(dx, dy, dz, qvx, qvy, qvz) * inv_det;
+					if (v < 0.0f || u + v > 1.0f) continue;
+					const float tt = dot3(t.edge2.x, t.edge2.y, t.edge2.z, qvx, qvy, qvz) * inv_det;
+					// glsl:124 accepts t_min <= t < best_t; an exact tie goes to the lower triangle id
+					if (!(tt < ray.t_min) && (tt < best_t || (tt == best_t && best_tri != UINT32_MAX && t.id < best_id))) {
+						best_t = tt; best_u = u; best_v = v; best_tri = ti; best_id = t.id;
+						if (any_hit) goto done;
+					}
+				}
+				if (sp == 0) break;
+				cur = stack[--sp];
+				continue;
+			}
+			if (stats) stats->bvh_nodes_visited++;
+			const uint32_t l = n.left_first, r = l + 1u;
+			float tl, tr;
+			const bool hl = slab(nodes_[l], ix, iy, iz, nrx, nry, nrz, ray.t_min, best_t, tl);
+			const bool hr = slab(nodes_[r], ix, iy, iz, nrx, nry, nrz, ray.t_min, best_t, tr);
+			if (hl && hr) { // near child first, far child pushed (glsl:290-305)
+				const bool left_near = tl < tr;
+				if (sp < 128) stack[sp++] = left_near ? r : l;
+				cur = left_near ? l : r;
+			} else if (hl) cur = l;
+			else if (hr) cur = r;
+			else { if (sp == 0) break; cur = stack[--sp]; }
+		}
+	done:
+		if (best_tri != UINT32_MAX) { // packed -> Intersection, gpu_ray_caster.cpp:442-456
+			const Triangle &t = tris_[best_tri];
+			out.t = best_t;
+			out.position = Vector3(ox + dx * best_t, oy + dy * best_t, oz + dz * best_t);
+			out.normal = t.normal; out.u = best_u; out.v = best_v; out.prim_id = t.id; out.hit_layers = t.layers;
+			if (stats) stats->hits++;
+		}
+		return out;
+	}
+
+private:
+	const Triangle *tris_; const mrt_bvh_node32 *nodes_; const uint32_t *prim_idx_; uint32_t n_tris_;
+
+	static float safe_inv(float d) // safe_inv_direction, glsl:137-145 == Ray::_precompute, src/core/ray.h:78-89
+	{
+		const float eps = 1e-9f, big = 1.0f / eps;
+		return std::fabs(d) > eps ? 1.0f / d : (d >= 0.0f ? big : -big);
+	}
+	static float dot3(float ax, float ay, float az, float bx, float by, float bz) { return std::fmaf(ax, bx, std::fmaf(ay, by, az * bz)); }
+	// ray_aabb, glsl:84-99, clamped to [t_min, best_t]
+	static bool slab(const mrt_bvh_node32 &b, float ix, float iy, float iz, float nrx, float nry, float nrz, float t_min, float best_t, float &tnear)
+	{
+		const float x0 = std::fmaf(b.aabb_min[0], ix, nrx), x1 = std::fmaf(b.aabb_max[0], ix, nrx);
+		const float y0 = std::fmaf(b.aabb_min[1], iy, nry), y1 = std::fmaf(b.aabb_max[1], iy, nry);
+		const float z0 = std::fmaf(b.aabb_min[2], iz, nrz), z1 = std::fmaf(b.aabb_max[2], iz, nrz);
+		tnear = std::fmax(std::fmax(std::fmin(x0, x1), std::fmin(y0, y1)), std::fmax(std::fmin(z0, z1), t_min));
+		const float tfar = std::fmin(std::fmin(std::fmax(x0, x1), std::fmax(y0, y1)), std::fmin(std::fmax(z0, z1), best_t));
+		return tnear <= tfar;
+	}
+};
+
+} // namespace mrt

@@ -6,7 +6,8 @@
 // usage: host_mirror_test <in.bin> <out.bin>
 //   in : u32 n_tris, f32 verts[n_tris*9], u32 n_rays, Ray rays[n_rays] (60 B each)
 //   out: i32 header[8], then Intersection[n] coherent, Intersection[n] sorted,
-//        u8[n] any-hit, Intersection[n] async, Intersection single, Intersection[n] after a device-side rebuild
+//        u8[n] any-hit, Intersection[n] async, Intersection single, Intersection[n] after a device-side rebuild,
+//        Intersection[n] from the CPU backend (Backend::CPU, the router's default, selected explicitly)
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
@@ -30,10 +31,12 @@ int main(int argc, char **argv)
 
 	RayDispatcher disp;
 	int header[8] = {0};
-	// 1. CPU backend is not provided: must fail loudly, not fall back.
+	// 1. Backend::GPU / AUTO before any device is initialised: must fail loudly (MRT_ERR_NO_DEVICE), not fall back to the CPU.
 	{
 		std::vector<Intersection> tmp(n_rays);
+		disp.set_backend(RayDispatcher::Backend::AUTO);
 		header[0] = disp.cast_rays(rays.data(), tmp.data(), (int)n_rays);
+		disp.set_backend(RayDispatcher::Backend::CPU);
 	}
 	// 2. flatten + id rule of _rebuild_scene (raytracer_server.cpp:700-711): running ids, layers all ones.
 	for (uint32_t i = 0; i < n_tris; i++) {
@@ -67,6 +70,12 @@ int main(int argc, char **argv)
 	if (!disp.using_gpu()) { std::fprintf(stderr, "device build left no scene\n"); return 6; }
 	disp.cast_rays(rays.data(), device_built.data(), (int)n_rays, nullptr, 0xFFFFFFFF, false);
 
+	// 5. the router's other backend, selected explicitly: the same records from the CPU pool
+	std::vector<Intersection> cpu(n_rays);
+	disp.set_backend(RayDispatcher::Backend::CPU);
+	RayStats cpu_stats;
+	if (disp.cast_rays(rays.data(), cpu.data(), (int)n_rays, &cpu_stats) != MRT_OK || cpu_stats.rays_cast != n_rays) { std::fprintf(stderr, "CPU backend broken\n"); return 7; }
+
 	FILE *o = std::fopen(argv[2], "wb");
 	if (!o) return 2;
 	std::fwrite(header, 4, 8, o);
@@ -76,6 +85,7 @@ int main(int argc, char **argv)
 	std::fwrite((const void *)async_res.data(), sizeof(Intersection), n_rays, o);
 	std::fwrite((const void *)&single, sizeof(Intersection), 1, o);
 	std::fwrite((const void *)device_built.data(), sizeof(Intersection), n_rays, o);
+	std::fwrite((const void *)cpu.data(), sizeof(Intersection), n_rays, o);
 	std::fclose(o);
 	return 0;
 }

@@ -8,16 +8,19 @@
 // collect_gpu_nearest / submit_gpu_async_any_hit / collect_gpu_any_hit /
 // has_gpu_pending, triangle_count / bvh_node_count / bvh_depth.
 //
-// What is NOT here, on purpose: the CPU backend.  In the reference the CPU
-// path is TinyBVH under a ThreadPool (ray_dispatcher.h:152-180,443-463); a
-// maintainer keeps that code as is.  This library ships only the device path
-// and never falls back to a CPU: with Backend::CPU, or with the GPU
-// unavailable, every cast returns MRT_ERR_UNSUPPORTED and prints why.  The
-// casts therefore return an int status (the reference's return void).
+// Backends.  GPU: the MI355X path through the C-ABI (gpu_ray_caster.hpp).  CPU: what the reference routes to its
+// ThreadPool + TinyBVH (ray_dispatcher.h:152-180,214-240,443-463) — here cpu_backend.hpp: the same range split
+// over a persistent pool, per-chunk RayStats merged afterwards, a BVH2 walk with the device kernels' arithmetic over the
+// arrays the device is fed, so both backends return the same records.  It is an EXPLICIT backend: the caller
+// selects Backend::CPU (the reference's default, kept).  Nothing degrades to it silently: Backend::GPU without a
+// device, and Backend::AUTO without one, return MRT_ERR_NO_DEVICE and say so (the reference's AUTO falls back to
+// its CPU pool; this library's rule is that the device path fails loudly).  The casts therefore return an int status
+// (the reference's return void).
 #pragma once
 #include <cstdint>
 #include <cstdio>
 #include <vector>
+#include "cpu_backend.hpp"
 #include "gpu_ray_caster.hpp"
 
 namespace mrt {
@@ -81,7 +84,11 @@ public:
 			uint32_t query_mask = 0xFFFFFFFF, bool coherent = false)
 	{
 		if (count < 0 || (count > 0 && (!rays || !results))) return MRT_ERR_INVALID;
-		if (!using_gpu()) return _no_cpu("cast_rays");
+		if (count == 0) return MRT_OK; // a silent no-op on every backend (gpu_ray_caster.cpp:419)
+		if (backend_ == Backend::CPU) {
+			return _cpu_dispatch(count, stats, [&](const CpuWalker &w, int i, RayStats *s) { results[i] = w.cast(rays[i], query_mask, false, s); });
+		}
+		if (!using_gpu()) return _no_device("cast_rays");
 		if (!coherent && count >= MIN_BATCH_FOR_SORTING) gpu_caster_.cast_rays_sorted(rays, results, count, query_mask);
 		else gpu_caster_.cast_rays(rays, results, count, query_mask);
 		if (stats) stats->rays_cast += (uint64_t)count;
@@ -92,7 +99,11 @@ public:
 			uint32_t query_mask = 0xFFFFFFFF, bool coherent = false)
 	{
 		if (count < 0 || (count > 0 && (!rays || !hit_results))) return MRT_ERR_INVALID;
-		if (!using_gpu()) return _no_cpu("any_hit_rays");
+		if (count == 0) return MRT_OK;
+		if (backend_ == Backend::CPU) {
+			return _cpu_dispatch(count, stats, [&](const CpuWalker &w, int i, RayStats *s) { hit_results[i] = w.cast(rays[i], query_mask, true, s).hit(); });
+		}
+		if (!using_gpu()) return _no_device("any_hit_rays");
 		if (!coherent && count >= MIN_BATCH_FOR_SORTING) gpu_caster_.cast_rays_any_hit_sorted(rays, hit_results, count, query_mask);
 		else gpu_caster_.cast_rays_any_hit(rays, hit_results, count, query_mask);
 		if (stats) stats->rays_cast += (uint64_t)count;
@@ -102,15 +113,17 @@ public:
 	Intersection cast_ray(const Ray &ray, RayStats *stats = nullptr, uint32_t query_mask = 0xFFFFFFFF)
 	{
 		Intersection result;
-		if (using_gpu()) { gpu_caster_.cast_rays(&ray, &result, 1, query_mask); if (stats) stats->rays_cast++; }
-		else _no_cpu("cast_ray");
+		if (backend_ == Backend::CPU) { if (scene_.built) result = _walker().cast(ray, query_mask, false, stats); }
+		else if (using_gpu()) { gpu_caster_.cast_rays(&ray, &result, 1, query_mask); if (stats) stats->rays_cast++; }
+		else _no_device("cast_ray");
 		return result;
 	}
 	bool any_hit(const Ray &ray, RayStats *stats = nullptr, uint32_t query_mask = 0xFFFFFFFF)
 	{
 		bool result = false;
-		if (using_gpu()) { gpu_caster_.cast_rays_any_hit(&ray, &result, 1, query_mask); if (stats) stats->rays_cast++; }
-		else _no_cpu("any_hit");
+		if (backend_ == Backend::CPU) { if (scene_.built) result = _walker().cast(ray, query_mask, true, stats).hit(); }
+		else if (using_gpu()) { gpu_caster_.cast_rays_any_hit(&ray, &result, 1, query_mask); if (stats) stats->rays_cast++; }
+		else _no_device("any_hit");
 		return result;
 	}
 
@@ -140,7 +153,7 @@ public:
 		while ((1 << depth) < nodes) depth++;
 		return depth;
 	}
-	uint32_t thread_count() const { return 0; } // no CPU pool in this backend
+	uint32_t thread_count() const { return pool_.thread_count(); } // workers of the CPU backend's pool (ray_dispatcher.h:386-388)
 
 	GPURayCaster &gpu_caster() { return gpu_caster_; }
 	const GPURayCaster &gpu_caster() const { return gpu_caster_; }
@@ -148,8 +161,36 @@ public:
 private:
 	RayScene scene_;
 	GPURayCaster gpu_caster_;
+	ThreadPool pool_;            // persistent worker threads of the CPU backend (ray_dispatcher.h:403)
 	Backend backend_ = Backend::CPU;
-	static constexpr int MIN_BATCH_FOR_SORTING = 256; // ray_dispatcher.h:427
+	static constexpr int MIN_BATCH_FOR_THREADING = 128; // ray_dispatcher.h:422
+	static constexpr int MIN_BATCH_FOR_SORTING = 256;   // ray_dispatcher.h:427
+
+	CpuWalker _walker() const
+	{
+		return CpuWalker(scene_.triangles.data(), scene_.bvh2.data(), scene_.prim_idx.data(), (uint32_t)scene_.triangles.size());
+	}
+	// ray_dispatcher.h:152-180: without stats one parallel dispatch; with stats every chunk accumulates into its own
+	// slot (taken from an atomic counter) and the slots are merged afterwards
+	template <typename PerRay>
+	int _cpu_dispatch(int count, RayStats *stats, PerRay per_ray)
+	{
+		if (count == 0) return MRT_OK;
+		if (!scene_.built) { std::fprintf(stderr, "[RayDispatcher] CPU backend: no scene built\n"); return MRT_ERR_NO_SCENE; }
+		const CpuWalker w = _walker();
+		if (!stats) {
+			pool_.dispatch_and_wait(count, MIN_BATCH_FOR_THREADING, [&](int start, int end) { for (int i = start; i < end; i++) per_ray(w, i, nullptr); });
+			return MRT_OK;
+		}
+		std::vector<RayStats> chunk_stats(pool_.thread_count() + 1);
+		std::atomic<uint32_t> slot_counter{0};
+		pool_.dispatch_and_wait(count, MIN_BATCH_FOR_THREADING, [&](int start, int end) {
+			RayStats &local = chunk_stats[slot_counter.fetch_add(1, std::memory_order_relaxed)];
+			for (int i = start; i < end; i++) per_ray(w, i, &local);
+		});
+		for (const auto &cs : chunk_stats) *stats += cs;
+		return MRT_OK;
+	}
 
 	bool _should_use_gpu() const // ray_dispatcher.h:429-439
 	{
@@ -160,11 +201,12 @@ private:
 		}
 		return false;
 	}
-	int _no_cpu(const char *what) const
+	int _no_device(const char *what) const
 	{
-		std::fprintf(stderr, "[RayDispatcher] %s: the CPU backend is the reference's own TinyBVH path and is not part of "
-				"this library; select Backend::GPU with an initialized, uploaded scene\n", what);
-		return MRT_ERR_UNSUPPORTED;
+		std::fprintf(stderr, "[RayDispatcher] %s: Backend::%s selected but no initialized MI355X context with an uploaded scene; "
+				"nothing falls back to the CPU silently (select Backend::CPU to use the CPU backend)\n", what,
+				backend_ == Backend::AUTO ? "AUTO" : "GPU");
+		return MRT_ERR_NO_DEVICE;
 	}
 };
 

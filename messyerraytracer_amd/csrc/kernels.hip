@@ -689,7 +689,7 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 
 // Persistent lane kernel: `blocks` workgroups stay resident and pull rays from *next_ray.
 hipError_t launch_trace_persistent(const TraceParams &p, unsigned long long *next_ray, uint32_t *overflow,
-		uint32_t lds_depth, uint32_t refill, uint32_t leaf_wait, uint32_t blocks, bool any_hit, hipStream_t stream)
+		uint32_t lds_depth, uint32_t refill, uint32_t leaf_wait, uint32_t blocks, bool any_hit, bool count, hipStream_t stream)
 {
 	if (p.count == 0 || blocks == 0) return hipSuccess;
 	PersistParams q;
@@ -707,6 +707,12 @@ hipError_t launch_trace_persistent(const TraceParams &p, unsigned long long *nex
 	} else if (p.kernel == MRT_KERNEL_TWO_LEVEL_PERSISTENT || p.kernel == MRT_KERNEL_TWO_LEVEL_PERSISTENT8) {
 		if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true, 2, true>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
 		else hipLaunchKernelGGL((trace_lane_persistent_kernel<false, 2, true>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
+	} else if (count) { // counting builds (flat scenes)
+#define MRT_LP(A, W) hipLaunchKernelGGL((trace_lane_persistent_kernel<A, W, false, true>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q)
+		if (wide8) { if (any_hit) MRT_LP(true, 8); else MRT_LP(false, 8); }
+		else if (wide4) { if (any_hit) MRT_LP(true, 4); else MRT_LP(false, 4); }
+		else { if (any_hit) MRT_LP(true, 2); else MRT_LP(false, 2); }
+#undef MRT_LP
 	} else if (wide8) {
 		if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true, 8>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
 		else hipLaunchKernelGGL((trace_lane_persistent_kernel<false, 8>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);

@@ -60,9 +60,20 @@ __device__ __forceinline__ float ubyte_f(uint32_t w, int k) { return (float)((w 
 // DevInstance rows, a lane inside an instance walks with its mesh-space ray and the marker kInstanceReturn on
 // its stack takes it back to the world ray.  WIDTH 2: both levels 2-wide.  WIDTH 8: the TLAS 2-wide, every
 // BLAS in the 8-wide compressed layout (p.nodes8, p.leaf_box; DevInstance::root8).
-template <bool ANY_HIT, int WIDTH, bool TL = false> // WIDTH: children per node step = 2 (DevNode), 4 (Dev4Node) or 8 (Dev8Node)
+// sum of a per-lane count over the wave (counting builds)
+__device__ __forceinline__ unsigned long long wave_sum(uint32_t v)
+{
+	unsigned long long s = v;
+	for (int m = 1; m < MRT_WAVE; m <<= 1) s += __shfl_xor(s, m);
+	return s;
+}
+
+// COUNT: the counting build (mrt_options.count_visits): per ray node steps (= cache lines fetched: one 64- or 128-byte
+// line per step whatever the width), triangle rows tested and, for the 8-wide walk, exact leaf boxes read.
+template <bool ANY_HIT, int WIDTH, bool TL = false, bool COUNT = false> // WIDTH: children per node step = 2 (DevNode), 4 (Dev4Node) or 8 (Dev8Node)
 __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent_kernel(const TraceParams p, const PersistParams q)
 {
+	uint32_t n_rays = 0, n_hits = 0, n_nodes = 0, n_tris = 0, n_boxchk = 0; // COUNT: this lane's totals over all its rays
 	static_assert(!TL || WIDTH == 2 || WIDTH == 8, "two-level scenes: 2-wide, or 8-wide inside the instances (the TLAS is always 2-wide)");
 	constexpr uint32_t kNode = TL ? kInstanceReturn : kSentinel; // refs below this are inner nodes
 	extern __shared__ uint32_t lds_stack[];
@@ -179,7 +190,17 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 				}
 			}
 		}
-		if (__ballot(has_ray) == 0ull) break; // no lane holds a ray and none is left to fetch
+		if (__ballot(has_ray) == 0ull) { // no lane holds a ray and none is left to fetch
+			if (COUNT) {
+				const unsigned long long a = wave_sum(n_rays), b = wave_sum(n_tris), c = wave_sum(n_nodes), d = wave_sum(n_hits), e = wave_sum(n_boxchk);
+				if (lane == 0u) {
+					atomicAdd(&p.counters[kCntRays], a); atomicAdd(&p.counters[kCntTris], b); atomicAdd(&p.counters[kCntNodes], c);
+					atomicAdd(&p.counters[kCntHits], d); atomicAdd(&p.counters[kCntWaveNodeFetch], c); atomicAdd(&p.counters[kCntWaveTriFetch], b);
+					atomicAdd(&p.counters[kCntLeafBoxChecks], e);
+				}
+			}
+			break;
+		}
 
 		// ---- traverse until enough lanes have finished to make a refill worthwhile ----
 		for (;;) {
@@ -193,6 +214,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 					cur = pop();
 				}
 				if (WIDTH == 8 && (!TL || in_blas) && cur < kNode) { // 8-wide compressed node: one 128-byte line, 96 bytes read
+					if (COUNT) n_nodes++;
 					const float4 *n = nodes8 + (size_t)cur * 8u;
 					const float4 h = n[0], qa = n[1], qb = n[2], qc = n[3], ra = n[4], rb = n[5];
 					const uint32_t meta = __float_as_uint(h.w);
@@ -251,6 +273,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 					}
 				}
 				if (WIDTH == 4 && cur < kSentinel) { // 4-wide collapse: one 128-byte line per step
+					if (COUNT) n_nodes++;
 					const float4 *n = nodes4 + (size_t)cur * 8u;
 					const float4 b0 = n[0], b1 = n[1], b2 = n[2], b3 = n[3], b4 = n[4], b5 = n[5], refs = n[6];
 					// child c box: min = (m[6c], m[6c+1], m[6c+2]), max = (m[6c+3], m[6c+4], m[6c+5])
@@ -285,6 +308,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 					}
 				}
 				if ((WIDTH == 2 || (TL && !in_blas)) && cur < kNode) { // dual-AABB node: glsl:243-318 (TL: every TLAS node)
+					if (COUNT) n_nodes++;
 					const float4 *n = nodes + (size_t)cur * 4u;
 					const float4 a = n[0], b = n[1], c = n[2], d = n[3];
 					const float l0x = fma_(a.x, ix, nrx), l1x = fma_(b.x, ix, nrx);
@@ -342,6 +366,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 					const float4 q0 = t3[0], q1 = t3[1], q2 = t3[2];
 					last = (__float_as_uint(q2.w) & kLastInLeaf) != 0u;
 					if (TL || (__float_as_uint(q1.w) & p.query_mask) != 0u) { // TL: the mask was applied to the instance
+						if (COUNT) n_tris++;
 						const float pvx = fma_(tdy, q2.z, -(tdz * q2.y));
 						const float pvy = fma_(tdz, q2.x, -(tdx * q2.z));
 						const float pvz = fma_(tdx, q2.y, -(tdy * q2.x));
@@ -367,6 +392,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 										// the same t in different leaves: the lower id has to win whichever came first).
 										bool entered = true;
 										if (WIDTH == 8) {
+											if (COUNT) n_boxchk++;
 											const float4 *lb = leaf_box + (size_t)leaf_first * 2u;
 											const float4 mn = lb[0], mx = lb[1];
 											const float x0 = fma_(mn.x, ix, nrx), x1 = fma_(mx.x, ix, nrx);

@@ -17,11 +17,24 @@ Two gates ("Parity"):
 """
 import numpy as np
 
-T_REL_TOL = 1e-5          # north_star tolerance on t / position
-T_REL_OUTLIER = 2e-4      # hard bound for ill-conditioned rays
-OUTLIER_FRACTION = 1e-4   # at most this fraction of rays may exceed T_REL_TOL
-MISMATCH_FRACTION = 1e-4  # at most this fraction of rays may differ in prim_id (all must be explained)
-EDGE_MARGIN = 5e-3        # |min(u, v, 1-u-v)| below this is an edge graze in fp32
+# Gates sit at about twice what was measured against the reference (oracle vs TinyBVH BVH8, tools in
+# tests/golden/make_golden.py): prim_id mismatches 1.7e-5 of the rays of the full C2 grid (0 / 0 / 1 / 2 of the
+# 16 384 sampled rays of C2 / C3 / C4 / C5), relative t error 3.4e-5 at worst on the full C2 grid (4.1e-6 on the
+# samples), 5e-6 of the rays above 1e-5.
+T_REL_TOL = 1e-5          # north_star tolerance on t / position; also the near-tie bound (|ta - tb| <= 1e-5 t)
+T_REL_OUTLIER = 5e-5      # hard bound for ill-conditioned rays
+OUTLIER_FRACTION = 2e-5   # at most this fraction of rays may exceed T_REL_TOL
+MISMATCH_FRACTION = 5e-5  # at most this fraction of rays may differ in prim_id (every one must be explained in fp64)
+# An edge graze: the fp64 barycentric margin min(u, v, 1-u-v) of the disputed hit is within what fp32 Moller-Trumbore
+# can resolve for THIS ray and triangle: the cancellation in tv = o - v0 and in the cross products loses
+# log2(|o - v0| / |edge|) bits, so the bound is EDGE_ULPS units in the last place of that ratio (C3: 12 / 0.1 -> 1e-4;
+# C5's triangles of 0.012 seen from 17 units away -> 1.4e-3; measured worst case there 3.7e-4), never above EDGE_MARGIN_CAP.
+EDGE_ULPS = 16.0
+EDGE_MARGIN_CAP = 5e-3
+# the two-level walk against the flat walk over the flattened scene (tests/test_two_level_*): the mesh-space ray
+# carries the rounding of the inverse transform (measured: 2.4e-5 of the common hits above 1e-5, 1.9e-4 at worst)
+TWO_LEVEL_T_REL_OUTLIER = 2e-4
+TWO_LEVEL_OUTLIER_FRACTION = 1e-4
 
 
 def mt64(tri, ray):
@@ -43,10 +56,17 @@ def mt64(tri, ray):
     return t, u, v, det
 
 
-def _edge_or_range(t, u, v, ray):
+def edge_margin(tri, ray):
+    """What |min(u, v, 1-u-v)| fp32 arithmetic can resolve for this ray and triangle (see EDGE_ULPS)."""
+    dist = float(np.linalg.norm(ray["origin"].astype(np.float64) - tri["v0"].astype(np.float64)))
+    edge = min(float(np.linalg.norm(tri["edge1"].astype(np.float64))), float(np.linalg.norm(tri["edge2"].astype(np.float64))))
+    return min(EDGE_MARGIN_CAP, EDGE_ULPS * 2.0 ** -24 * max(1.0, dist / max(edge, 1e-30)))
+
+
+def _edge_or_range(t, u, v, ray, tri):
     margin = min(u, v, 1.0 - u - v)
-    near_edge = abs(margin) <= EDGE_MARGIN
-    near_tmin = abs(t - float(ray["t_min"])) <= 1e-4 * max(1.0, abs(t))
+    near_edge = abs(margin) <= edge_margin(tri, ray)
+    near_tmin = abs(t - float(ray["t_min"])) <= T_REL_TOL * max(1.0, abs(t))
     return near_edge or near_tmin
 
 
@@ -59,11 +79,11 @@ def explain_mismatch(tris_by_id, ray, prim_a, prim_b):
         return True
     if ta is None or tb is None:
         t, u, v, _ = ta if ta is not None else tb
-        return _edge_or_range(t, u, v, ray)
+        return _edge_or_range(t, u, v, ray, tris_by_id[prim_a if ta is not None else prim_b])
     if abs(ta[0] - tb[0]) <= T_REL_TOL * max(abs(ta[0]), abs(tb[0])):
         return True  # near tie
-    nearer = ta if ta[0] < tb[0] else tb
-    return _edge_or_range(nearer[0], nearer[1], nearer[2], ray)
+    nearer, tri = (ta, tris_by_id[prim_a]) if ta[0] < tb[0] else (tb, tris_by_id[prim_b])
+    return _edge_or_range(nearer[0], nearer[1], nearer[2], ray, tri)
 
 
 def assert_exact(got, want, what=""):
@@ -104,5 +124,7 @@ def assert_reference_parity(got_prim, got_t, ref_prim, ref_t, rays, tris, what="
         frac = float((rel > T_REL_TOL).mean())
         assert (rel > T_REL_TOL).sum() <= max(2, int(OUTLIER_FRACTION * n)), \
             f"{what}: {frac:.3g} of rays exceed {T_REL_TOL} relative t error"
-    return dict(mismatches=int(diff.size), max_rel_t=float(rel.max()) if rel.size else 0.0,
-                outliers=int((rel > T_REL_TOL).sum()) if rel.size else 0)
+    st = dict(rays=int(n), mismatches=int(diff.size), sub_tmin_reference_hits=int(below_tmin.sum()) if below_tmin.size else 0,
+              max_rel_t=float(rel.max()) if rel.size else 0.0, outliers=int((rel > T_REL_TOL).sum()) if rel.size else 0)
+    print(f"[parity] {what}: {st}")
+    return st

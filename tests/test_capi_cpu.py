@@ -15,7 +15,7 @@ from oracle import pyoracle as po
 
 def test_library_exports_every_declared_symbol(built):
     hdr = open(os.path.join(ROOT, "include", "mrt_hip.h")).read()
-    declared = sorted(set(re.findall(r"^(?:int|void|uint32_t|const char \*)\s*(mrt_[a-z0-9_]+)\(", hdr, re.M)))
+    declared = sorted(set(re.findall(r"^(?:int|void|uint32_t|const char \*|mrt_ctx \*)\s*(mrt_[a-z0-9_]+)\(", hdr, re.M)))
     assert declared, "no declarations parsed"
     assert sorted(capi.SYMBOLS) == declared, "capi.SYMBOLS out of sync with include/mrt_hip.h"
     L = capi.load()

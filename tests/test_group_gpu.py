@@ -1,0 +1,60 @@
+"""mrt_group_cast_grid: a grid's rows sharded over the members of a group equals one device's cast of the whole grid,
+byte for byte.  A one-GPU box exercises the multi-member path with several members on device 0 (separate contexts,
+streams, token buffers, peer copies onto the same device)."""
+import numpy as np
+import pytest
+
+from messyerraytracer_amd import capi, synth, types as T
+from oracle import pyoracle as po
+import parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("members", [[0], [0, 0], [0, 0, 0, 0, 0]])
+@pytest.mark.parametrize("wh", [(256, 192), (250, 101)])
+def test_group_grid_equals_one_device(ctx, members, wh):
+    w, h = wh
+    verts = synth.soup(30000, 0.2, 17)
+    scene = capi.Scene(verts)
+    scene.upload(ctx)
+    cam = capi.camera_look((0, 0, -12), (0, 0, 1), w, h, 50.0)
+    want = ctx.cast_grid(cam, w, h)
+    parity.assert_exact(want, po.OracleScene(verts).trace(po.grid_rays((0, 0, -12), (0, 0, 1), w, h, 50.0)), "one device vs oracle")
+    g = capi.Group(members)
+    assert g.size() == len(members)
+    g.upload(scene)
+    got = g.cast_grid(cam, w, h)
+    assert got.tobytes() == want.tobytes(), "sharded over the group vs one device"
+    # a RayCamera grid, any-hit bools, records left on member 0's device
+    rcam = capi.ray_camera((1.0, 0.5, 12.0), np.eye(3, dtype=np.float32), w, h, 45.0)
+    assert g.cast_grid(rcam, w, h).tobytes() == ctx.cast_grid(rcam, w, h).tobytes()
+    b = g.cast_grid(cam, w, h, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT)
+    assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
+    d = ctx.device_alloc(w * h * 32)
+    g.cast_grid(cam, w, h, hits=d, flags=capi.FLAG_HITS_ON_DEVICE)
+    back = np.zeros(w * h, dtype=T.HIT32)
+    ctx.d2h(back, d)
+    ctx.device_free(d)
+    assert back.tobytes() == want.tobytes()
+    with pytest.raises(capi.MrtError):
+        g.cast_grid(cam, w, h, flags=capi.FLAG_TOKEN_OUT)
+    g.close()
+
+
+def test_group_two_level_scene(ctx):
+    local, inst = synth.multi_mesh_instances(5, 700, 0.3, 9)
+    ctx.upload_two_level_scene(local, inst)
+    w, h = 200, 120
+    cam = capi.camera_look((0, 0, -12), (0, 0, 1), w, h, 50.0)
+    want = ctx.cast_grid(cam, w, h)
+    g = capi.Group([0, 0, 0])
+    g.upload_two_level_scene(local, inst)
+    assert g.cast_grid(cam, w, h).tobytes() == want.tobytes()   # (records travel: tokens need a flat scene)
+    g.close()
+
+
+def test_group_rejects_a_missing_device(built):
+    with pytest.raises(capi.MrtError) as e:
+        capi.Group([0, 99])
+    assert e.value.status == capi.ERR_NO_DEVICE

@@ -36,7 +36,7 @@ def test_ray_dispatcher_mirror(built, scene):
             f.write(host.tobytes())
         r = subprocess.run([exe, fin, fout], capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
-        assert "CPU backend" in r.stderr  # Backend::CPU failed loudly instead of falling back
+        assert "nothing falls back to the CPU silently" in r.stderr  # Backend::AUTO without a device failed loudly
         raw = open(fout, "rb").read()
     header = np.frombuffer(raw[:32], dtype=np.int32)
     off = 32
@@ -45,8 +45,9 @@ def test_ray_dispatcher_mirror(built, scene):
     any_hit = np.frombuffer(raw[off:off + n], dtype=np.uint8).astype(bool); off += n
     async_ = np.frombuffer(raw[off:off + 44 * n], dtype=T.HOST_HIT44); off += 44 * n
     single = np.frombuffer(raw[off:off + 44], dtype=T.HOST_HIT44); off += 44
-    device_built = np.frombuffer(raw[off:off + 44 * n], dtype=T.HOST_HIT44)
-    assert header[0] == 8            # MRT_ERR_UNSUPPORTED for the CPU backend
+    device_built = np.frombuffer(raw[off:off + 44 * n], dtype=T.HOST_HIT44); off += 44 * n
+    cpu = np.frombuffer(raw[off:off + 44 * n], dtype=T.HOST_HIT44)
+    assert header[0] == 2            # MRT_ERR_NO_DEVICE: Backend::AUTO with no initialised device does not degrade to the CPU
     assert header[1] == 1 and header[2] == v.shape[0]
     assert header[5] == 0 and header[6] == 0 and header[7] == 0
     osc = po.OracleScene(v)
@@ -58,3 +59,4 @@ def test_ray_dispatcher_mirror(built, scene):
     assert np.array_equal(any_hit, want["prim_id"] != 0xFFFFFFFF)
     assert single.tobytes() == want[:1].tobytes()
     assert device_built.tobytes() == want.tobytes()  # GPURayCaster::build_scene_on_device: same records
+    assert cpu.tobytes() == want.tobytes()           # Backend::CPU (explicit): the same records as the device, bit for bit

@@ -155,8 +155,8 @@ def test_two_level_agrees_with_the_flattened_scene(built):
     assert int(hit.sum()) > 10000
     ta, tb = a["t"][hit].astype(np.float64), b["t"][hit].astype(np.float64)
     err = np.abs(ta - tb)
-    assert (err > 1e-5 * np.maximum(ta, 1.0)).mean() <= parity.OUTLIER_FRACTION   # grazing hits are ill-conditioned in both walks
-    assert (err <= parity.T_REL_OUTLIER * np.maximum(ta, 1.0)).all()
+    assert (err > 1e-5 * np.maximum(ta, 1.0)).mean() <= parity.TWO_LEVEL_OUTLIER_FRACTION   # grazing hits are ill-conditioned in both walks
+    assert (err <= parity.TWO_LEVEL_T_REL_OUTLIER * np.maximum(ta, 1.0)).all()
     assert np.abs(a["normal"][hit] - b["normal"][hit]).max() <= 2e-4
     assert np.array_equal(a["hit_layers"][hit], b["hit_layers"][hit])
     c1.close(); c2.close()

@@ -52,12 +52,6 @@ def main():
         rd_raw, wr = pmc["FETCH_SIZE"] * 1024.0, pmc["WRITE_SIZE"] * 1024.0
         summary["hbm_bytes_per_launch"] = {"read_raw": rd_raw, "read_x2_gfx950": 2 * rd_raw, "write": wr,
                                            "total_upper": 2 * rd_raw + wr}
-        tp = os.path.join(out_dir, "pmc_traffic.json")
-        traffic = json.load(open(tp)) if os.path.exists(tp) else {}
-        traffic[config] = {"hbm_bytes_per_launch": 2 * rd_raw + wr, "read_raw": rd_raw, "write": wr, "round": tag,
-                           "kernel": summary.get("kernel_name"),
-                           "note": "FETCH_SIZE*1024*2 (gfx950 half-count correction) + WRITE_SIZE*1024, mean over profiled launches"}
-        json.dump(traffic, open(tp, "w"), indent=1, sort_keys=True)
     # effective shader clock of the profiled dispatches (guide, "DVFS give-back"): GRBM_GUI_ACTIVE sums the 8 XCDs
     if "GRBM_GUI_ACTIVE" in pmc:
         clk = [c / 8.0 / d for c, d in zip(counters["GRBM_GUI_ACTIVE"], durations["GRBM_GUI_ACTIVE"]) if d > 0]  # GHz
@@ -85,6 +79,22 @@ def main():
         if "SQ_WAVES" in pmc:
             summary["per_wave"] = {k: pmc[k] / pmc["SQ_WAVES"] for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_LDS",
                                                                            "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR") if k in pmc}
+    if "hbm_bytes_per_launch" in summary:
+        tp = os.path.join(out_dir, "pmc_traffic.json")
+        traffic = json.load(open(tp)) if os.path.exists(tp) else {}
+        hb = summary["hbm_bytes_per_launch"]
+        rec = {"hbm_bytes_per_launch": hb["total_upper"], "read_raw": hb["read_raw"], "write": hb["write"], "round": tag,
+               "kernel": summary.get("kernel_name"),
+               "note": "FETCH_SIZE*1024*2 (gfx950 half-count correction) + WRITE_SIZE*1024, mean over profiled launches"}
+        b = summary.get("bench_line_under_rocprof", {})
+        if b.get("roofline", {}).get("rays_per_step_rank0"):
+            rec["rays_per_launch"] = b["roofline"]["rays_per_step_rank0"]
+        if "SQ_INSTS_VALU" in pmc:
+            rec["valu_insts_per_launch"] = pmc["SQ_INSTS_VALU"]
+        if "effective_clock_ghz" in summary:
+            rec["clock_ghz"] = summary["effective_clock_ghz"]
+        traffic[config] = rec
+        json.dump(traffic, open(tp, "w"), indent=1, sort_keys=True)
     with open(os.path.join(out_dir, f"{tag}_summary.json"), "w") as f:
         json.dump(summary, f, indent=1)
     print(json.dumps(summary, indent=1))
