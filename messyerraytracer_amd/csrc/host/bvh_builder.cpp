@@ -341,7 +341,7 @@ extern "C" int mrt_bvh2_load(const char *path, uint32_t n_tris, mrt_bvh_node32 *
 	if (!f) return MRT_ERR_INVALID;
 	CacheHeader h;
 	int rc = MRT_ERR_BAD_BVH;
-	if (std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, kCacheMagic, 8) == 0 && h.version == kCacheVersion &&
+	if (std::fread(&h, sizeof(h), 1, f) == 1 && std::memcmp(h.magic, kCacheMagic, 8) == 0 && h.version == kCacheVersion && h.reserved == 0u &&
 			h.n_tris == n_tris && h.used_nodes >= 1 && (uint64_t)h.used_nodes <= 2ull * n_tris) { // the caller's array holds 2 n_tris nodes
 		if (std::fread(nodes, sizeof(mrt_bvh_node32), h.used_nodes, f) == h.used_nodes &&
 				std::fread(prim_idx, 4, n_tris, f) == n_tris && std::fgetc(f) == EOF &&

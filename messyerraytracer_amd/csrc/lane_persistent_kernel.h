@@ -134,6 +134,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 				nx = nn.x; ny = nn.y; nz = nn.z;
 			}
 			if (!TL) store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
+			if (COUNT) { n_rays++; if (best_slot != 0xFFFFFFFFu) n_hits++; }
 			has_ray = false;
 		}
 		const unsigned long long idle_mask = __ballot(idle);

@@ -110,7 +110,7 @@
 // Ends with cur = the child to visit next (an inner node, or a leaf = its first triangle row, bit 31 set) and the
 // mask of the lanes whose own ray hit that child in the packet's mask register; or with the packet's pop bit set
 // in %[ev].  A pushed entry is 16 bytes {ref, -, lane mask}.
-#define MRT_ROWS_NODE_STEP(P, RS, POPBIT, BX, BY, BZ)                                                                 \
+#define MRT_ROWS_NODE_STEP(P, RS, POPBIT, CNT_P, BX, BY, BZ)                                                                 \
 	MRT_ROWS_SLAB(P, RS, BX, BY, BZ)                                                                                \
 	"v_cmp_le_f32 vcc, v50, v53\n"           /* lanes that hit the left child  */                                  \
 	"v_cmp_le_f32_e64 s[54:55], v56, v52\n"  /* lanes that hit the right child */                                  \
@@ -129,6 +129,7 @@
 	"ds_write_b32 " MRT_OP("sp", P) ", v51\n"                                                                       \
 	"ds_write_b64 " MRT_OP("sp", P) ", v[52:53] offset:8\n"                                                         \
 	"v_add_u32 " MRT_OP("sp", P) ", 16, " MRT_OP("sp", P) "\n"                                                      \
+	CNT_P                                                                                                           \
 	"v_lshlrev_b32 v54, 6, v51\n"            /* pull the pushed row (node, or the leaf's first triangle) towards */ \
 	"global_load_dword v60, v54, %[rows]\n"  /* the L2 now; v60 is never read (vmcnt drained at the very end)    */ \
 	"s_branch L_" P "done_%=\n"                                                                                     \
@@ -257,11 +258,11 @@
 	"s_branch L_" P "done_%=\n"
 
 // a step of packet P, whatever its current row is
-#define MRT_ROWS_STEP(P, RS, POPBIT, CNT_N, CNT_T, ANYHIT_CODE, BX, BY, BZ)                                            \
+#define MRT_ROWS_STEP(P, RS, POPBIT, CNT_N, CNT_T, CNT_P, ANYHIT_CODE, BX, BY, BZ)                                            \
 	"s_bitcmp1_b32 " MRT_OP("cur", P) ", 31\n"                                                                      \
 	"s_cbranch_scc1 L_" P "tri_%=\n"                                                                                \
 	CNT_N                                                                                                           \
-	MRT_ROWS_NODE_STEP(P, RS, POPBIT, BX, BY, BZ)                                                                    \
+	MRT_ROWS_NODE_STEP(P, RS, POPBIT, CNT_P, BX, BY, BZ)                                                             \
 	"s_branch L_" P "done_%=\n"                                                                                     \
 	"L_" P "tri_%=:\n"                                                                                              \
 	MRT_ROWS_TRI_STEP(P, RS, POPBIT, CNT_T, ANYHIT_CODE)                                                             \
@@ -311,7 +312,7 @@ struct PacketRegs {
 
 // ---- the loops ------------------------------------------------------------------------------------------------
 // One packet (register set A).  In: cur = a row to visit.  Out: cur = 0x7FFFFFFF.
-#define MRT_ROWS_LOOP1(CNT_N, CNT_T, T_PRE, T_POST, ANYHIT_CODE, BX, BY, BZ)                                          \
+#define MRT_ROWS_LOOP1(CNT_N, CNT_T, CNT_P, T_PRE, T_POST, ANYHIT_CODE, BX, BY, BZ)                                          \
 	asm volatile(                                                                                                   \
 		"s_mov_b64 s[60:61], %[maskA]\n"                                                                            \
 		"L_loop_%=:\n"                                                                                              \
@@ -320,7 +321,7 @@ struct PacketRegs {
 		"s_load_dwordx16 s[20:35], %[rows], s52\n"                                                                  \
 		"s_waitcnt lgkmcnt(0)\n"                                                                                    \
 		T_POST                                                                                                      \
-		MRT_ROWS_STEP("A", RA, "1", CNT_N, CNT_T, ANYHIT_CODE, BX, BY, BZ)                                          \
+		MRT_ROWS_STEP("A", RA, "1", CNT_N, CNT_T, CNT_P, ANYHIT_CODE, BX, BY, BZ)                                   \
 		"s_cmp_eq_u32 %[ev], 0\n"                                                                                   \
 		"s_cbranch_scc1 L_loop_%=\n"                                                                                \
 		MRT_ROWS_POP_ISSUE("A", "0", "v[50:53]")                                                                    \
@@ -331,7 +332,7 @@ struct PacketRegs {
 		"s_cbranch_scc1 L_loop_%=\n"                                                                                \
 		"s_waitcnt vmcnt(0)\n"               /* no prefetch may land in v60 once the compiler owns it again */     \
 		"s_mov_b64 %[maskA], s[60:61]\n"                                                                            \
-		: MRT_ROWS_OUT(A, a), [ev] "+s"(ev), [cntn] "+s"(cnt_n), [cntt] "+s"(cnt_t), [cntw] "+s"(cnt_w)             \
+		: MRT_ROWS_OUT(A, a), [ev] "+s"(ev), [cntn] "+s"(cnt_n), [cntt] "+s"(cnt_t), [cntw] "+s"(cnt_w), [cntp] "+s"(sp_max) \
 		: MRT_ROWS_IN(A, a), [rows] "s"(rows), [qmask] "s"(qmask), [eps] "s"(eps), [vneg] "v"(vneg)                 \
 		: MRT_ROWS_CLOBBERS)
 
@@ -365,7 +366,7 @@ struct PacketRegs {
 
 // In: cur (group A's operand) = a row to visit, the groups' own masks.  Out: cur = 0x7FFFFFFF.
 // Stack entries are 32 bytes: {group A's mask, group B's mask, ref, -}; the sentinel entry has ref 0x7FFFFFFF.
-#define MRT_ROWS_LOOPW(CNT_N, CNT_T, ANYA, ANYB, ANYDONE, BX, BY, BZ)                                                 \
+#define MRT_ROWS_LOOPW(CNT_N, CNT_T, CNT_P, ANYA, ANYB, ANYDONE, BX, BY, BZ)                                                 \
 	asm volatile(                                                                                                   \
 		"s_mov_b64 s[60:61], %[maskA]\n"                                                                            \
 		"s_mov_b64 s[62:63], %[maskB]\n"                                                                            \
@@ -399,6 +400,7 @@ struct PacketRegs {
 		"ds_write_b128 %[spA], v[50:53]\n"                                                                          \
 		"ds_write_b32 %[spA], v54 offset:16\n"                                                                      \
 		"v_add_u32 %[spA], 32, %[spA]\n"                                                                            \
+		CNT_P                                                                                                       \
 		"v_lshlrev_b32 v55, 6, v54\n"           /* pull the pushed row towards the L2 now */                        \
 		"global_load_dword v60, v55, %[rows]\n" /* v60 is never read (vmcnt drained at the very end) */             \
 		"s_branch L_loop_%=\n"                                                                                      \
@@ -447,7 +449,7 @@ struct PacketRegs {
 		"s_mov_b64 %[maskA], s[60:61]\n"                                                                            \
 		"s_mov_b64 %[maskB], s[62:63]\n"                                                                            \
 		: MRT_ROWS_OUT(A, a), [limB] "+v"(b.lim), [btB] "+v"(b.bt), [buB] "+v"(b.bu), [bvB] "+v"(b.bv),             \
-		  [bsB] "+v"(b.bs), [biB] "+v"(b.bi), [maskB] "+s"(b.mask), [cntn] "+s"(cnt_n), [cntt] "+s"(cnt_t)          \
+		  [bsB] "+v"(b.bs), [biB] "+v"(b.bi), [maskB] "+s"(b.mask), [cntn] "+s"(cnt_n), [cntt] "+s"(cnt_t), [cntp] "+s"(sp_max) \
 		: MRT_ROWS_IN(A, a), MRT_ROWS_IN(B, b), [rows] "s"(rows), [qmask] "s"(qmask), [eps] "s"(eps), [vneg] "v"(vneg) \
 		: MRT_ROWS_CLOBBERS)
 
@@ -456,6 +458,7 @@ struct PacketRegs {
 #define MRT_ROWS_T_PRE "s_memtime s[64:65]\n s_waitcnt lgkmcnt(0)\n"
 #define MRT_ROWS_T_POST "s_memtime s[66:67]\n s_waitcnt lgkmcnt(0)\n s_sub_u32 s64, s66, s64\n s_add_u32 %[cntw], %[cntw], s64\n"
 #define MRT_ROWS_CNT_N "s_add_u32 %[cntn], %[cntn], 1\n"
+#define MRT_ROWS_CNT_P "v_readfirstlane_b32 s52, %[spA]\n s_max_u32 %[cntp], %[cntp], s52\n" /* counting builds: the stack's high-water mark */
 #define MRT_ROWS_CNT_T "s_add_u32 %[cntt], %[cntt], 1\n"
 
 // wave-uniform operands come back from an asm block as SGPRs; this tells the compiler they still are
@@ -467,38 +470,40 @@ __device__ __forceinline__ void rows_uniform(PacketRegs &s)
 }
 
 template <int OCT, bool ANY_HIT, bool COUNT>
-__device__ __forceinline__ void rows_walk_one(const float4 *rows, uint32_t qmask, PacketRegs &a, uint32_t &cnt_n, uint32_t &cnt_t, uint32_t &cnt_w)
+__device__ __forceinline__ void rows_walk_one(const float4 *rows, uint32_t qmask, PacketRegs &a, uint32_t &cnt_n, uint32_t &cnt_t, uint32_t &cnt_w, uint32_t &sp_max)
 {
 	const float eps = 1e-8f, vneg = -FLT_MAX;
 	uint32_t ev = 0u;
 #define MRT_W1(O, BX, BY, BZ)                                                                                         \
 	if (OCT == O) {                                                                                                 \
-		if (COUNT) { if (ANY_HIT) MRT_ROWS_LOOP1(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWS_T_PRE, MRT_ROWS_T_POST, MRT_ROWS_ANYHIT("A", "4"), BX, BY, BZ); \
-			else MRT_ROWS_LOOP1(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWS_T_PRE, MRT_ROWS_T_POST, MRT_ROWS_NEAREST("A"), BX, BY, BZ); } \
-		else { if (ANY_HIT) MRT_ROWS_LOOP1("", "", "", "", MRT_ROWS_ANYHIT("A", "4"), BX, BY, BZ);                  \
-			else MRT_ROWS_LOOP1("", "", "", "", MRT_ROWS_NEAREST("A"), BX, BY, BZ); }                               \
+		if (COUNT) { if (ANY_HIT) MRT_ROWS_LOOP1(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWS_CNT_P, MRT_ROWS_T_PRE, MRT_ROWS_T_POST, MRT_ROWS_ANYHIT("A", "4"), BX, BY, BZ); \
+			else MRT_ROWS_LOOP1(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWS_CNT_P, MRT_ROWS_T_PRE, MRT_ROWS_T_POST, MRT_ROWS_NEAREST("A"), BX, BY, BZ); } \
+		else { if (ANY_HIT) MRT_ROWS_LOOP1("", "", "", "", "", MRT_ROWS_ANYHIT("A", "4"), BX, BY, BZ);              \
+			else MRT_ROWS_LOOP1("", "", "", "", "", MRT_ROWS_NEAREST("A"), BX, BY, BZ); }                           \
 	}
 	MRT_W1(0, 0, 0, 0) MRT_W1(1, 1, 0, 0) MRT_W1(2, 0, 1, 0) MRT_W1(3, 1, 1, 0) MRT_W1(4, 0, 0, 1) MRT_W1(5, 1, 0, 1) MRT_W1(6, 0, 1, 1) MRT_W1(7, 1, 1, 1)
 #undef MRT_W1
 	rows_uniform(a);
 	cnt_n = __builtin_amdgcn_readfirstlane(cnt_n); cnt_t = __builtin_amdgcn_readfirstlane(cnt_t); cnt_w = __builtin_amdgcn_readfirstlane(cnt_w);
+	sp_max = __builtin_amdgcn_readfirstlane(sp_max);
 }
 
 template <int OCT, bool ANY_HIT, bool COUNT>
-__device__ __forceinline__ void rows_walk_wide(const float4 *rows, uint32_t qmask, PacketRegs &a, PacketRegs &b, uint32_t &cnt_n, uint32_t &cnt_t)
+__device__ __forceinline__ void rows_walk_wide(const float4 *rows, uint32_t qmask, PacketRegs &a, PacketRegs &b, uint32_t &cnt_n, uint32_t &cnt_t, uint32_t &sp_max)
 {
 	const float eps = 1e-8f, vneg = -FLT_MAX;
 #define MRT_WW(O, BX, BY, BZ)                                                                                         \
 	if (OCT == O) {                                                                                                 \
-		if (COUNT) { if (ANY_HIT) MRT_ROWS_LOOPW(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWSW_ANYHIT("A"), MRT_ROWSW_ANYHIT("B"), MRT_ROWSW_ANYDONE, BX, BY, BZ); \
-			else MRT_ROWS_LOOPW(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWS_NEAREST("A"), MRT_ROWS_NEAREST("B"), "", BX, BY, BZ); } \
-		else { if (ANY_HIT) MRT_ROWS_LOOPW("", "", MRT_ROWSW_ANYHIT("A"), MRT_ROWSW_ANYHIT("B"), MRT_ROWSW_ANYDONE, BX, BY, BZ); \
-			else MRT_ROWS_LOOPW("", "", MRT_ROWS_NEAREST("A"), MRT_ROWS_NEAREST("B"), "", BX, BY, BZ); }            \
+		if (COUNT) { if (ANY_HIT) MRT_ROWS_LOOPW(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWS_CNT_P, MRT_ROWSW_ANYHIT("A"), MRT_ROWSW_ANYHIT("B"), MRT_ROWSW_ANYDONE, BX, BY, BZ); \
+			else MRT_ROWS_LOOPW(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWS_CNT_P, MRT_ROWS_NEAREST("A"), MRT_ROWS_NEAREST("B"), "", BX, BY, BZ); } \
+		else { if (ANY_HIT) MRT_ROWS_LOOPW("", "", "", MRT_ROWSW_ANYHIT("A"), MRT_ROWSW_ANYHIT("B"), MRT_ROWSW_ANYDONE, BX, BY, BZ); \
+			else MRT_ROWS_LOOPW("", "", "", MRT_ROWS_NEAREST("A"), MRT_ROWS_NEAREST("B"), "", BX, BY, BZ); }        \
 	}
 	MRT_WW(0, 0, 0, 0) MRT_WW(1, 1, 0, 0) MRT_WW(2, 0, 1, 0) MRT_WW(3, 1, 1, 0) MRT_WW(4, 0, 0, 1) MRT_WW(5, 1, 0, 1) MRT_WW(6, 0, 1, 1) MRT_WW(7, 1, 1, 1)
 #undef MRT_WW
 	rows_uniform(a);
 	cnt_n = __builtin_amdgcn_readfirstlane(cnt_n); cnt_t = __builtin_amdgcn_readfirstlane(cnt_t);
+	sp_max = __builtin_amdgcn_readfirstlane(sp_max);
 }
 
 __device__ __forceinline__ void rows_init(PacketRegs &s, const RayRegs &r, bool takes_part, uint32_t sp)
@@ -564,6 +569,7 @@ __global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS
 	const int oct_b = PACKETS == 2 ? rows_octant(rb, valid_b, part_b) : 8;
 	uint32_t cnt_n = 0u, cnt_t = 0u; // COUNT: node rows / triangle rows fetched by this wave
 	uint32_t cnt_w = 0u;             // COUNT, one-packet loop: shader cycles between issuing a row fetch and having it
+	uint32_t sp_wide = 0u, sp_one = 0u; // COUNT: highest stack pointers seen (LDS byte addresses) by the 128-ray / the one-packet walk
 	const unsigned long long t_start = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
 	bool done_a = part_a == 0ull, done_b = part_b == 0ull;
 	if (PACKETS == 2 && !done_a && !done_b && oct_a == oct_b && oct_a != 8) {
@@ -572,13 +578,13 @@ __global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS
 		*(volatile uint32_t *)&stack_a[4] = kSentinel;
 		A.sp += 16u; // (= stack base + 32)
 		A.mask = part_a; B.mask = part_b;
-#define MRT_RW2(O) case O: rows_walk_wide<O, ANY_HIT, COUNT>(rows, p.query_mask, A, B, cnt_n, cnt_t); break;
+#define MRT_RW2(O) case O: rows_walk_wide<O, ANY_HIT, COUNT>(rows, p.query_mask, A, B, cnt_n, cnt_t, sp_wide); break;
 		switch (oct_a) { MRT_RW2(0) MRT_RW2(1) MRT_RW2(2) MRT_RW2(3) MRT_RW2(4) MRT_RW2(5) MRT_RW2(6) MRT_RW2(7) }
 #undef MRT_RW2
 		done_a = done_b = true;
 	}
 	// packets that could not be paired (different octants: tiles on an image axis; a single packet): one at a time
-#define MRT_RW1(O, S) case O: rows_walk_one<O, ANY_HIT, COUNT>(rows, p.query_mask, S, cnt_n, cnt_t, cnt_w); break;
+#define MRT_RW1(O, S) case O: rows_walk_one<O, ANY_HIT, COUNT>(rows, p.query_mask, S, cnt_n, cnt_t, cnt_w, sp_one); break;
 	if (!done_a && oct_a != 8) { switch (oct_a) { MRT_RW1(0, A) MRT_RW1(1, A) MRT_RW1(2, A) MRT_RW1(3, A) MRT_RW1(4, A) MRT_RW1(5, A) MRT_RW1(6, A) MRT_RW1(7, A) } done_a = true; }
 	if (PACKETS == 2 && !done_b && oct_b != 8) { switch (oct_b) { MRT_RW1(0, B) MRT_RW1(1, B) MRT_RW1(2, B) MRT_RW1(3, B) MRT_RW1(4, B) MRT_RW1(5, B) MRT_RW1(6, B) MRT_RW1(7, B) } done_b = true; }
 #undef MRT_RW1
@@ -606,6 +612,11 @@ __global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS
 		atomicAdd(&p.counters[kCntFetchWaitCycles], (unsigned long long)cnt_w);
 		atomicAdd(&p.counters[kCntWaveCycles], __builtin_amdgcn_s_memtime() - t_start);
 		atomicAdd(&p.counters[kCntWaves], 1ull);
+	}
+	if (COUNT && p.count_mode != 2u) { // the stack's high-water mark, in entries (the bound is the uploaded BVH's depth, <= 64: api.hip)
+		const uint32_t base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)stack_a;
+		const uint32_t e_wide = sp_wide > base ? (sp_wide - base) / 32u : 0u, e_one = sp_one > base ? ((sp_one - base) % 1040u) / 16u : 0u;
+		atomicMax(&p.counters[kCntMaxStack], (unsigned long long)(e_wide > e_one ? e_wide : e_one));
 	}
 	if (COUNT && p.count_mode != 2u) { // (count_visits = 2: the clock only, sampled, so that the counting itself does not load the memory system)
 		// per-ray words: every step of the wave is charged to every ray of the wave (both packets): an upper bound

@@ -185,6 +185,44 @@ def test_ragged_batch_sizes(ctx, soup1k, count):
     parity.assert_exact(ctx.cast(rays), want, f"n={count} sorted")
 
 
+@pytest.mark.parametrize("kernel", [capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_ROWS, capi.KERNEL_PACKET_DUAL])
+def test_partial_waves_and_clipped_tiles_on_every_packet_kernel(built, kernel):
+    """Packets whose wave is not full: COHERENT batches of 1 .. 1000 rays (the last wave partial; at count = 1 lanes
+    1..63 have no ray) and grids whose right and bottom tiles are clipped, on the flat and the two-level packet walks.
+    Pins the abort of round 1 (gpurun_out/test6.log: a 4-wide packet kernel, since retired, selected child refs with
+    v_readlane from lanes 1..3, which had EXITED for want of a ray and held stale registers: wild node index, memory
+    fault, SIGABRT inside mrt_cast at count = 1).  No surviving kernel reads another lane's registers except through
+    v_readfirstlane (first ACTIVE lane) and ballots; this test keeps it that way."""
+    v = synth.soup(3000, 0.4, 8)
+    scene, osc = capi.Scene(v), po.OracleScene(v)
+    c = capi.Context(0, kernel=kernel)
+    scene.upload(c)
+    rays = po.grid_rays((0, 0, -12), (0, 0, 1), 40, 25, 50.0)
+    want = osc.trace(rays)
+    for count in (1, 2, 63, 65, 129, 1000):
+        parity.assert_exact(c.cast(rays[:count], flags=capi.FLAG_COHERENT), want[:count], f"kernel {kernel}, {count} coherent rays")
+    for (w, h) in ((13, 5), (8, 8), (9, 17), (130, 3)):   # tiles clipped on the right and at the bottom; an odd number of tiles
+        cam = capi.camera_look((0, 0, -12), (0, 0, 1), w, h, 50.0)
+        g = po.grid_rays((0, 0, -12), (0, 0, 1), w, h, 50.0)
+        parity.assert_exact(c.cast_grid(cam, w, h), osc.trace(g), f"kernel {kernel}, {w}x{h} grid")
+        parity.assert_exact(c.cast_grid(cam, w, h, y0=1, y1=h - 1), osc.trace(g[w:(h - 1) * w]), f"kernel {kernel}, {w}x{h} rows 1..h-1")
+        any_got = c.cast_grid(cam, w, h, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT).astype(bool)
+        assert np.array_equal(any_got, osc.trace(g)["prim_id"] >= 0)
+    # the two-level packet walk (its BLAS walks are the single-packet asm loop)
+    local, inst = synth.multi_mesh_instances(4, 600, 0.3, 13)
+    c.upload_two_level_scene(local, inst)
+    tl = po.OracleTwoLevelScene(local, inst)
+    for (w, h) in ((13, 5), (9, 17)):
+        cam = capi.camera_look((0, 0, -12), (0, 0, 1), w, h, 50.0)
+        g = po.grid_rays((0, 0, -12), (0, 0, 1), w, h, 50.0)
+        got, wt = c.cast_grid(cam, w, h), tl.trace(g)
+        assert np.array_equal(got["prim_id"], wt["prim_id"]) and np.array_equal(got["t"], wt["t"])
+    wt = tl.trace(rays[:65])
+    got = c.cast(rays[:65], flags=capi.FLAG_COHERENT)
+    assert np.array_equal(got["prim_id"], wt["prim_id"]) and np.array_equal(got["t"], wt["t"])
+    c.close()
+
+
 def test_empty_and_errors(built):
     c = capi.Context(0)
     rays = synth.incoherent_rays(10, 1)
@@ -313,6 +351,8 @@ def test_counting_variant_matches_oracle_counters(built):
         # a packet needs at least what its hungriest ray needs, and at most what its 64 (128) rays need together
         assert ctr["node_visits"] / rays.shape[0] <= s["wave_node_fetches"] / n_packets * (2 if kern == capi.KERNEL_PACKET_DUAL else 1)
         assert 0 < s["wave_node_fetches"] <= ctr["node_visits"] and 0 < s["wave_tri_fetches"] <= ctr["tri_tests"] * 64
+        if kern != capi.KERNEL_PACKET_ASM:   # the row walks record their stack's high-water mark: never above what the BVH can need
+            assert 0 < s["max_stack_depth"] <= c.scene_info()["stack_need"], (s["max_stack_depth"], c.scene_info())
         c.close()
     # ... and the persistent lane kernels: node steps = cache lines fetched, per ray
     inc = synth.incoherent_rays(100000, 31)
