@@ -209,6 +209,9 @@ enum {
 	                               triangles), TWO packets per wave in lockstep: twice the fetches in flight at the same
 	                               occupancy (the packet walk is latency-bound); default for coherent batches        */
 	MRT_KERNEL_PACKET_ROWS = 10, /* the same walk with one packet per wave                                           */
+	MRT_KERNEL_PACKET_QUAD = 11, /* the 128-ray shared walk over FOUR-wide node rows (128 bytes: the 4-wide collapse of the
+	                                same tree, exact boxes): half the row fetches for the same box tests
+	                                (packet_quad_kernel.h); needs the 4-wide layout resident                     */
 	/* reported in mrt_stats.last_kernel only (chosen by the library for two-level scenes, not selectable): */
 	MRT_KERNEL_TWO_LEVEL = 100, MRT_KERNEL_TWO_LEVEL_PACKET = 101, MRT_KERNEL_TWO_LEVEL_PERSISTENT = 102,
 	MRT_KERNEL_TWO_LEVEL_PERSISTENT8 = 103

@@ -12,7 +12,7 @@ HOST_CPU_TEST = os.path.join(HERE, "host_cpu_test")
 
 SOURCES = ["kernels.hip", "api.hip", "group.hip", "device_build.hip", "host/scene_prep.cpp", "host/bvh_builder.cpp",
            "host/two_level_prep.cpp"]
-HEADERS = ["mrt_internal.h", "packet_kernel.h", "packet_asm_kernel.h", "packet_rows_kernel.h", "two_level_kernel.h", "lane_persistent_kernel.h", "../../include/mrt_hip.h", "host/gpu_ray_caster.hpp", "host/ray_dispatcher.hpp",
+HEADERS = ["mrt_internal.h", "packet_kernel.h", "packet_asm_kernel.h", "packet_rows_kernel.h", "packet_quad_kernel.h", "two_level_kernel.h", "lane_persistent_kernel.h", "../../include/mrt_hip.h", "host/gpu_ray_caster.hpp", "host/ray_dispatcher.hpp",
            "host/host_types.hpp", "host/cpu_backend.hpp", "host/ray_tracer_server.hpp"]
 # -Xarch_host -mfma: explicit fmaf() calls of the host code (the 8-wide collapse verifies every quantised
 # box with the kernel's own fma) become one instruction instead of a libm call; nothing is contracted

@@ -21,7 +21,7 @@ FLAG_COHERENT, FLAG_RAYS_ON_DEVICE, FLAG_HITS_ON_DEVICE, FLAG_HOST_LAYOUT, FLAG_
 TOKEN_MISS = 0xFFFFFFFF
 BUILD_TRIS_ON_DEVICE, BUILD_SAFE_HANDOFF, BUILD_BLAS_ON_DEVICE = 1, 2, 4
 KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET = 0, 1, 2   # (3 and 4: retired experiments, ids not reused)
-KERNEL_PACKET_ASM, KERNEL_LANE_PERSISTENT, KERNEL_LANE4_PERSISTENT, KERNEL_LANE8_PERSISTENT, KERNEL_PACKET_DUAL, KERNEL_PACKET_ROWS = 5, 6, 7, 8, 9, 10
+KERNEL_PACKET_ASM, KERNEL_LANE_PERSISTENT, KERNEL_LANE4_PERSISTENT, KERNEL_LANE8_PERSISTENT, KERNEL_PACKET_DUAL, KERNEL_PACKET_ROWS, KERNEL_PACKET_QUAD = 5, 6, 7, 8, 9, 10, 11
 KERNEL_TWO_LEVEL, KERNEL_TWO_LEVEL_PACKET, KERNEL_TWO_LEVEL_PERSISTENT, KERNEL_TWO_LEVEL_PERSISTENT8 = 100, 101, 102, 103  # reported only
 
 # every entry point include/mrt_hip.h declares (tests check they are all exported)

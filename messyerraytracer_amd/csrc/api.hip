@@ -22,6 +22,8 @@
 namespace mrt {
 hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream);
 hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t stream);
+hipError_t launch_build_rows4(const Dev4Node *nodes4, const TriHot *hot, const TriCold *cold, uint32_t n_nodes4, uint32_t n_tris,
+		void *rows, hipStream_t stream);
 hipError_t launch_build_rows(const DevNode *nodes, const TriHot *hot, const TriCold *cold, uint32_t n_nodes, uint32_t n_tris,
 		void *rows, hipStream_t stream);
 hipError_t launch_expand_tokens(const TraceParams &p, const uint32_t *tokens, hipStream_t stream);
@@ -55,6 +57,7 @@ struct mrt_ctx {
 	mrt::Dev4Node *d_nodes4 = nullptr; uint32_t n_nodes4 = 0;
 	mrt::Dev8Node *d_nodes8 = nullptr; uint32_t n_nodes8 = 0, stack8 = 0;
 	float *d_leaf_box = nullptr; // exact leaf boxes that go with d_nodes8
+	void *d_rows4 = nullptr;     // flat scenes with the 4-wide layout: 128-byte node rows + triangle rows (packet_quad_kernel.h)
 	void *d_rows = nullptr;      // flat scenes: nodes + triangles as one array of 64-byte rows (packet_rows_kernel.h)
 	// two-level scene: d_nodes = TLAS + every BLAS, d_hot / d_cold = mesh-space triangles, d_instances in TLAS leaf order
 	mrt::DevInstance *d_instances = nullptr;
@@ -123,6 +126,8 @@ void free_scene(mrt_ctx *ctx)
 	ctx->d_leaf_box = nullptr;
 	if (ctx->d_rows) (void)hipFree(ctx->d_rows);
 	ctx->d_rows = nullptr;
+	if (ctx->d_rows4) (void)hipFree(ctx->d_rows4);
+	ctx->d_rows4 = nullptr;
 	if (ctx->d_instances) (void)hipFree(ctx->d_instances);
 	ctx->d_instances = nullptr;
 	if (ctx->two_level) { mrt::free_two_level(ctx->two_level); delete ctx->two_level; ctx->two_level = nullptr; }
@@ -149,7 +154,7 @@ uint32_t out_format(uint32_t flags, int mode)
 void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 {
 	std::memset(&p, 0, sizeof(p));
-	p.nodes = ctx->d_nodes; p.nodes4 = ctx->d_nodes4; p.nodes8 = ctx->d_nodes8; p.leaf_box = ctx->d_leaf_box; p.instances = ctx->d_instances; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold; p.row_array = ctx->d_rows;
+	p.nodes = ctx->d_nodes; p.nodes4 = ctx->d_nodes4; p.nodes8 = ctx->d_nodes8; p.leaf_box = ctx->d_leaf_box; p.instances = ctx->d_instances; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold; p.row_array = ctx->d_rows; p.row_array4 = ctx->d_rows4; p.tri_unit_base4 = 2u * ctx->n_nodes4;
 	p.stack_depth = ctx->stack_depth; p.n_tris = ctx->n_tris; p.n_nodes = ctx->n_nodes;
 	if (ctx->opts.stack_override >= ctx->depth && ctx->opts.stack_override <= 64) p.stack_depth = ctx->opts.stack_override;
 	p.counters = ctx->d_counters;
@@ -174,6 +179,8 @@ uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent, uint64_t count)
 	if (ctx->two_level) return coherent && ctx->opts.kernel != MRT_KERNEL_LANE ? mrt::MRT_KERNEL_TWO_LEVEL_PACKET : mrt::MRT_KERNEL_TWO_LEVEL;
 	if (ctx->opts.kernel == MRT_KERNEL_PACKET_DUAL || ctx->opts.kernel == MRT_KERNEL_PACKET_ROWS)
 		return !coherent ? MRT_KERNEL_LANE : (ctx->d_rows ? ctx->opts.kernel : MRT_KERNEL_PACKET_ASM);
+	if (ctx->opts.kernel == MRT_KERNEL_PACKET_QUAD)
+		return !coherent ? MRT_KERNEL_LANE : (ctx->d_rows4 ? MRT_KERNEL_PACKET_QUAD : MRT_KERNEL_PACKET_ASM);
 	if (ctx->opts.kernel >= MRT_KERNEL_LANE && ctx->opts.kernel <= MRT_KERNEL_LANE8_PERSISTENT) return ctx->opts.kernel;
 	if (!coherent) return MRT_KERNEL_LANE;
 	// Coherent batches: the 128-ray shared walk over the row array (packet_rows_kernel.h) once the batch is large
@@ -188,6 +195,16 @@ uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent, uint64_t count)
 // without (coherent batches then take trace_packet_asm_kernel).
 int build_rows(mrt_ctx *ctx)
 {
+	// the 4-wide rows: when the 4-wide layout is resident and its worst-case stack fits the wave's 64 entries
+	const bool wanted4 = ctx->opts.kernel == MRT_KERNEL_AUTO || ctx->opts.kernel == MRT_KERNEL_PACKET_QUAD;
+	const uint64_t n_units4 = (uint64_t)2u * ctx->n_nodes4 + ctx->n_tris;
+	if (wanted4 && ctx->d_nodes4 && ctx->n_nodes4 && ctx->stack4 <= 64u && n_units4 < mrt::kAsmNodeLimit) {
+		if (hipMalloc(&ctx->d_rows4, (size_t)n_units4 * 64u) != hipSuccess) { ctx->d_rows4 = nullptr; (void)hipGetLastError(); }
+		else {
+			HIP_TRY(ctx, mrt::launch_build_rows4(ctx->d_nodes4, ctx->d_hot, ctx->d_cold, ctx->n_nodes4, ctx->n_tris, ctx->d_rows4, ctx->stream));
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+		}
+	}
 	const bool wanted = ctx->opts.kernel == MRT_KERNEL_AUTO || ctx->opts.kernel == MRT_KERNEL_PACKET_DUAL || ctx->opts.kernel == MRT_KERNEL_PACKET_ROWS;
 	const uint64_t n_rows = (uint64_t)ctx->n_nodes + ctx->n_tris;
 	if (!wanted || n_rows >= mrt::kAsmNodeLimit) return MRT_OK;
@@ -483,6 +500,7 @@ const char *mrt_kernel_name(uint32_t kernel)
 		case MRT_KERNEL_PACKET_ASM: return "trace_packet_asm_kernel";
 		case MRT_KERNEL_PACKET_DUAL: return "trace_packet_rows_kernel<2>";
 		case MRT_KERNEL_PACKET_ROWS: return "trace_packet_rows_kernel<1>";
+		case MRT_KERNEL_PACKET_QUAD: return "trace_packet_quad_kernel";
 		case MRT_KERNEL_LANE_PERSISTENT: return "trace_lane_persistent_kernel<2>";
 		case MRT_KERNEL_LANE4_PERSISTENT: return "trace_lane_persistent_kernel<4>";
 		case MRT_KERNEL_LANE8_PERSISTENT: return "trace_lane_persistent_kernel<8>";
@@ -501,7 +519,7 @@ int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
 	if (!out) return MRT_ERR_INVALID;
 	*out = nullptr;
 	if (opts && opts->struct_size != sizeof(mrt_options)) return MRT_ERR_INVALID;
-	if (opts && (opts->kernel > MRT_KERNEL_PACKET_ROWS || opts->kernel == 3u || opts->kernel == 4u)) return MRT_ERR_INVALID; // 3, 4: retired ids
+	if (opts && (opts->kernel > MRT_KERNEL_PACKET_QUAD || opts->kernel == 3u || opts->kernel == 4u)) return MRT_ERR_INVALID; // 3, 4: retired ids
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || device_ordinal < 0 || device_ordinal >= n) return MRT_ERR_NO_DEVICE;
 	mrt_ctx *ctx = new (std::nothrow) mrt_ctx();
@@ -579,7 +597,7 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	free_scene(ctx);
 	hipError_t e;
 	// the 4-wide layout is resident only when a kernel that walks it is asked for
-	const bool want4 = ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_AUTO;
+	const bool want4 = ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_PACKET_QUAD || ctx->opts.kernel == MRT_KERNEL_AUTO;
 	if ((e = hipMalloc(&ctx->d_nodes, (size_t)h.n_nodes * sizeof(mrt::DevNode))) != hipSuccess ||
 			// +16 B of slack: a 64-B scalar fetch at the last 48-B triangle stays inside the allocation
 			(e = hipMalloc(&ctx->d_hot, (size_t)h.n_tris * sizeof(mrt::TriHot) + 16)) != hipSuccess ||
@@ -640,23 +658,27 @@ int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 		d_tris = (const mrt_tri64 *)staged;
 	}
 	mrt::DeviceBuildResult b;
-	const bool want4 = ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_AUTO;
+	const bool want4 = ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_PACKET_QUAD || ctx->opts.kernel == MRT_KERNEL_AUTO;
 	const bool want8 = ctx->opts.kernel == MRT_KERNEL_LANE8_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_AUTO;
 	rc = mrt::device_build_lbvh(d_tris, n_tris, want4, want8, (flags & MRT_BUILD_SAFE_HANDOFF) != 0, (void *)ctx->stream, &b,
 			ctx->err, sizeof(ctx->err));
 	if (staged) (void)hipFree(staged);
 	if (rc) return rc;
-	if (b.depth > 64) { // the packet kernels keep 64 stack entries per wave
+	auto drop_build = [&] { // the build's arrays are ours until the context takes them over below
 		(void)hipFree(b.nodes); (void)hipFree(b.hot); (void)hipFree(b.cold);
 		if (b.nodes4) (void)hipFree(b.nodes4);
 		if (b.nodes8) (void)hipFree(b.nodes8);
 		if (b.leaf_box) (void)hipFree(b.leaf_box);
+	};
+	if (b.depth > 64) { // the packet kernels keep 64 stack entries per wave
+		drop_build();
 		return fail(ctx, MRT_ERR_UNSUPPORTED, "device-built BVH deeper than the 64-entry traversal stack: build on the host");
 	}
-	HIP_TRY(ctx, hipEventRecord(e1, ctx->stream));
-	HIP_TRY(ctx, hipEventSynchronize(e1));
 	float ms = 0.0f;
-	HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+	hipError_t te = hipEventRecord(e1, ctx->stream);
+	if (te == hipSuccess) te = hipEventSynchronize(e1);
+	if (te == hipSuccess) te = hipEventElapsedTime(&ms, e0, e1);
+	if (te != hipSuccess) { drop_build(); return fail(ctx, MRT_ERR_HIP, hipGetErrorString(te)); }
 	free_scene(ctx);
 	ctx->d_nodes = b.nodes; ctx->d_hot = b.hot; ctx->d_cold = b.cold;
 	ctx->d_nodes4 = b.nodes4; ctx->n_nodes4 = b.nodes4 ? b.n_nodes : 0; ctx->stack4 = b.stack4;
@@ -796,11 +818,11 @@ int mrt_upload_two_level_scene(mrt_ctx *ctx, const float *verts9, uint32_t n_mes
 	auto drop = [&] { mrt::free_two_level(h); delete h; };
 	unsigned n_thr = std::thread::hardware_concurrency();
 	rc = mrt::prepare_two_level(verts9, n_mesh_tris, instances, n_instances, n_thr ? n_thr : 1u, !on_device, h, ctx->err, sizeof(ctx->err));
-	if (rc) { delete h; return rc; }
+	if (rc) { drop(); return rc; }
 	if (!on_device && h->depth > 64u) { drop(); return fail(ctx, MRT_ERR_UNSUPPORTED, "two-level scene: trees too deep for the traversal stack"); }
-	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+	hipError_t e = hipStreamSynchronize(ctx->stream);
+	if (e != hipSuccess) { drop(); return fail(ctx, MRT_ERR_HIP, hipGetErrorString(e)); }
 	free_scene(ctx);
-	hipError_t e;
 	if ((e = hipMalloc(&ctx->d_nodes, (size_t)h->n_nodes * sizeof(mrt::DevNode))) != hipSuccess ||
 			(e = hipMalloc(&ctx->d_hot, (size_t)h->n_tris * sizeof(mrt::TriHot) + 16)) != hipSuccess ||
 			(e = hipMalloc(&ctx->d_cold, (size_t)h->n_tris * sizeof(mrt::TriCold))) != hipSuccess ||
@@ -815,19 +837,17 @@ int mrt_upload_two_level_scene(mrt_ctx *ctx, const float *verts9, uint32_t n_mes
 		ctx->d_nodes8 = nullptr; ctx->d_leaf_box = nullptr; h->wide8 = false;
 	}
 	if (on_device) {
-		hipEvent_t e0, e1;
-		HIP_TRY(ctx, hipEventCreate(&e0)); HIP_TRY(ctx, hipEventCreate(&e1));
+		hipEvent_t e0 = ctx->ev[0], e1 = ctx->ev[1]; // the context's own events: nothing to create or to leak here
 		(void)hipEventRecord(e0, ctx->stream);
 		rc = build_blases_on_device(ctx, h, verts9);
 		if (!rc) rc = mrt::refit_two_level(h, instances, n_instances, ctx->err, sizeof(ctx->err));
 		if (!rc && h->depth > 64u) rc = fail(ctx, MRT_ERR_UNSUPPORTED, "two-level scene: device-built trees too deep for the traversal stack: build on the host");
-		if (rc) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); drop(); free_scene(ctx); return rc; }
+		if (rc) { drop(); free_scene(ctx); return rc; }
 		e = hipMemcpy(ctx->d_nodes, h->nodes, (size_t)h->n_tlas_nodes * sizeof(mrt::DevNode), hipMemcpyHostToDevice);
 		(void)hipEventRecord(e1, ctx->stream);
 		(void)hipEventSynchronize(e1);
 		float ms = 0.0f;
 		if (hipEventElapsedTime(&ms, e0, e1) == hipSuccess) ctx->stats.last_build_ms = ms;
-		(void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
 	} else {
 		e = hipMemcpy(ctx->d_nodes, h->nodes, (size_t)h->n_nodes * sizeof(mrt::DevNode), hipMemcpyHostToDevice);
 		if (e == hipSuccess) e = hipMemcpy(ctx->d_hot, h->hot, (size_t)h->n_tris * sizeof(mrt::TriHot), hipMemcpyHostToDevice);

@@ -353,6 +353,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 #include "packet_kernel.h"
 #include "packet_asm_kernel.h"
 #include "packet_rows_kernel.h"
+#include "packet_quad_kernel.h"
 #include "two_level_kernel.h"
 
 // ---- the unified row array of packet_rows_kernel.h ------------------------------------------------------------
@@ -387,6 +388,44 @@ hipError_t launch_build_rows(const DevNode *nodes, const TriHot *hot, const TriC
 	const uint64_t total = (uint64_t)n_nodes + n_tris;
 	hipLaunchKernelGGL(build_rows_kernel, dim3((uint32_t)((total + MRT_WG - 1) / MRT_WG)), dim3(MRT_WG), 0, stream,
 			nodes, hot, cold, n_nodes, n_tris, reinterpret_cast<float4 *>(rows));
+	return hipGetLastError();
+}
+
+// ---- the row array of packet_quad_kernel.h: units of 64 bytes; 4-wide node i = the 128-byte row at unit 2i with
+// its boxes as {min, max} pairs per axis and its refs rebased (inner -> 2 * index, leaf -> 0x80000000 |
+// (2 * n_nodes4 + first slot)); triangle slot s = the
+// 64-byte row at unit 2 * n_nodes4 + s ----
+__global__ __launch_bounds__(MRT_WG) void build_rows4_kernel(const Dev4Node *nodes4, const TriHot *hot, const TriCold *cold,
+		uint32_t n_nodes4, uint32_t n_tris, float4 *rows)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * MRT_WG + threadIdx.x;
+	if (g >= (uint64_t)n_nodes4 + n_tris) return;
+	if (g < n_nodes4) {
+		const Dev4Node &n = nodes4[g];
+		float *out = reinterpret_cast<float *>(rows + g * 8u);
+		for (int k = 0; k < 4; k++)
+			for (int c = 0; c < 3; c++) { out[6 * k + 2 * c] = n.box[k][c]; out[6 * k + 2 * c + 1] = n.box[k][3 + c]; } // {min, max} per axis
+		uint32_t *oref = reinterpret_cast<uint32_t *>(out) + 24;
+		for (int i = 0; i < 4; i++) {
+			const uint32_t ref = n.ref[i];
+			oref[i] = ref == kSentinel ? ref : (ref >= kLeafBit ? (kLeafBit | (2u * n_nodes4 + (ref & 0x7FFFFFFFu))) : 2u * ref);
+		}
+		oref[4] = n.n_children; oref[5] = 0u; oref[6] = 0u; oref[7] = 0u;
+	} else {
+		const uint64_t s = g - n_nodes4;
+		float4 *out = rows + ((uint64_t)2u * n_nodes4 + s) * 4u;
+		const float4 *t = reinterpret_cast<const float4 *>(hot) + s * 3u;
+		out[0] = t[0]; out[1] = t[1]; out[2] = t[2];
+		out[3] = reinterpret_cast<const float4 *>(cold)[s];
+	}
+}
+
+hipError_t launch_build_rows4(const Dev4Node *nodes4, const TriHot *hot, const TriCold *cold, uint32_t n_nodes4, uint32_t n_tris,
+		void *rows, hipStream_t stream)
+{
+	const uint64_t total = (uint64_t)n_nodes4 + n_tris;
+	hipLaunchKernelGGL(build_rows4_kernel, dim3((uint32_t)((total + MRT_WG - 1) / MRT_WG)), dim3(MRT_WG), 0, stream,
+			nodes4, hot, cold, n_nodes4, n_tris, reinterpret_cast<float4 *>(rows));
 	return hipGetLastError();
 }
 
@@ -641,6 +680,17 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		else hipLaunchKernelGGL((trace_two_level_kernel<false>), grid, wg, lds2, stream, p);
 		return hipGetLastError();
 	}
+	if (p.kernel == MRT_KERNEL_PACKET_QUAD && p.row_array4 != nullptr) {
+		// the 128-ray walk over 4-wide node rows: two packets per wave (half the waves)
+		const uint64_t rblocks = (threads + 2u * MRT_WG - 1) / (2u * MRT_WG);
+		dim3 rgrid((uint32_t)rblocks);
+		if (count) {
+			if (any_hit) hipLaunchKernelGGL((trace_packet_quad_kernel<true, true>), rgrid, wg, p.extra_lds, stream, p);
+			else hipLaunchKernelGGL((trace_packet_quad_kernel<false, true>), rgrid, wg, p.extra_lds, stream, p);
+		} else if (any_hit) hipLaunchKernelGGL((trace_packet_quad_kernel<true, false>), rgrid, wg, p.extra_lds, stream, p);
+		else hipLaunchKernelGGL((trace_packet_quad_kernel<false, false>), rgrid, wg, p.extra_lds, stream, p);
+		return hipGetLastError();
+	}
 	if ((p.kernel == MRT_KERNEL_PACKET_DUAL || p.kernel == MRT_KERNEL_PACKET_ROWS) && p.row_array != nullptr) {
 		// the walk over the unified row array: one or two packets per wave (two: half the waves)
 		const uint32_t packets = p.kernel == MRT_KERNEL_PACKET_DUAL ? 2u : 1u;
@@ -658,7 +708,7 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		return hipGetLastError();
 	}
 	// scenes whose node offsets pass the asm loop's 32 bits use the C++ packet kernel
-	if ((p.kernel == MRT_KERNEL_PACKET_ASM || p.kernel == MRT_KERNEL_PACKET_DUAL || p.kernel == MRT_KERNEL_PACKET_ROWS) && p.n_nodes < kAsmNodeLimit) {
+	if ((p.kernel == MRT_KERNEL_PACKET_ASM || p.kernel == MRT_KERNEL_PACKET_DUAL || p.kernel == MRT_KERNEL_PACKET_ROWS || p.kernel == MRT_KERNEL_PACKET_QUAD) && p.n_nodes < kAsmNodeLimit) {
 		if (count) {
 			if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true, true>), grid, wg, p.extra_lds, stream, p);
 			else hipLaunchKernelGGL((trace_packet_asm_kernel<false, true>), grid, wg, p.extra_lds, stream, p);
@@ -666,7 +716,7 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		else hipLaunchKernelGGL((trace_packet_asm_kernel<false>), grid, wg, p.extra_lds, stream, p);
 		return hipGetLastError();
 	}
-	if (p.kernel == MRT_KERNEL_PACKET || p.kernel == MRT_KERNEL_PACKET_ASM || p.kernel == MRT_KERNEL_PACKET_DUAL || p.kernel == MRT_KERNEL_PACKET_ROWS) {
+	if (p.kernel == MRT_KERNEL_PACKET || p.kernel == MRT_KERNEL_PACKET_ASM || p.kernel == MRT_KERNEL_PACKET_DUAL || p.kernel == MRT_KERNEL_PACKET_ROWS || p.kernel == MRT_KERNEL_PACKET_QUAD) {
 		if (any_hit) {
 			if (count) hipLaunchKernelGGL((trace_packet_kernel<true, true>), grid, wg, 0, stream, p);
 			else hipLaunchKernelGGL((trace_packet_kernel<true, false>), grid, wg, 0, stream, p);

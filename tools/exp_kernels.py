@@ -51,6 +51,8 @@ VARIANTS = {
     "dual_cast": (dict(kernel=capi.KERNEL_PACKET_DUAL), "cast"),
     "dual_fused_zorder": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=2), "fused"),
     "dual_fused_rowmajor": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=1), "fused"),
+    "quad_fused": (dict(kernel=capi.KERNEL_PACKET_QUAD), "fused"),
+    "quad_cast": (dict(kernel=capi.KERNEL_PACKET_QUAD), "cast"),
     "auto_cast": (dict(), "cast"),
     "auto_tiled": (dict(), "tiled"),
     "persist2_linear": (dict(kernel=capi.KERNEL_LANE_PERSISTENT), "cast"),
@@ -119,6 +121,14 @@ def main():
         summary[n] = dict(min_ms=float(v.min()), median_ms=float(np.median(v)), mrays=w * h / np.median(v) / 1e3)
         print(f"{n:28s} {v.min():9.3f} {np.median(v):10.3f} {w * h / np.median(v) / 1e3:13.1f}", flush=True)
     if a.count:
+        for kern in (capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_QUAD):
+            c = capi.Context(0, kernel=kern, count_visits=True)
+            scene.upload(c)
+            c.cast_grid(cam, w, h, hits=d_hits, flags=capi.FLAG_HITS_ON_DEVICE)
+            s = c.stats()
+            print("counting", capi.kernel_name(s["last_kernel"]), "node rows/packet %.1f tri rows/packet %.1f max_stack %d" % (
+                s["wave_node_fetches"] / (w * h / 128), s["wave_tri_fetches"] / (w * h / 128), s["max_stack_depth"]), flush=True)
+            c.close()
         for kern in (capi.KERNEL_LANE, capi.KERNEL_PACKET):
             c = capi.Context(0, kernel=kern, count_visits=True)
             scene.upload(c)

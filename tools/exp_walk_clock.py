@@ -23,7 +23,8 @@ def main():
     scene = capi.Scene(synth.scene_vertices(cfg))
     cam = capi.camera_look(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
     out = {}
-    for name, kern, mode in (("rows1_clock", capi.KERNEL_PACKET_ROWS, 2), ("rows2_clock", capi.KERNEL_PACKET_DUAL, 2), ("rows1_count", capi.KERNEL_PACKET_ROWS, 1)):
+    for name, kern, mode in (("rows1_clock", capi.KERNEL_PACKET_ROWS, 2), ("rows2_clock", capi.KERNEL_PACKET_DUAL, 2), ("quad_clock", capi.KERNEL_PACKET_QUAD, 2),
+                             ("rows1_count", capi.KERNEL_PACKET_ROWS, 1), ("rows2_count", capi.KERNEL_PACKET_DUAL, 1), ("quad_count", capi.KERNEL_PACKET_QUAD, 1)):
         ctx = capi.Context(0, kernel=kern, count_visits=mode)
         scene.upload(ctx)
         d_hits = ctx.device_alloc(w * h * 32)
