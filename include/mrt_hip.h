@@ -240,7 +240,10 @@ typedef struct mrt_options {
 	                             leaf (default 8 for the 8-wide walk, else 16; 64 = classic while-while) */
 	uint32_t extra_lds;       /* experiments: bytes of dynamic LDS added to every packet-kernel workgroup, which lowers
 	                             the number of resident waves (occupancy sweeps, tools/exp_occupancy.py); <= 60000 */
-	uint32_t reserved[3];
+	uint32_t packet_wg;       /* MRT_KERNEL_PACKET_DUAL: threads per workgroup, 64 or 256; 0 = by the size of the scene (64 up to
+	                             256 MB of nodes + triangles: wave slots refill one by one; 256 above: the four waves of a
+	                             workgroup walk neighbouring tiles through one scalar cache) */
+	uint32_t reserved[2];
 } mrt_options;
 
 typedef struct mrt_ctx mrt_ctx;

@@ -694,15 +694,19 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 	if ((p.kernel == MRT_KERNEL_PACKET_DUAL || p.kernel == MRT_KERNEL_PACKET_ROWS) && p.row_array != nullptr) {
 		// the walk over the unified row array: one or two packets per wave (two: half the waves)
 		const uint32_t packets = p.kernel == MRT_KERNEL_PACKET_DUAL ? 2u : 1u;
-		const uint64_t rblocks = (threads + packets * MRT_WG - 1) / (packets * MRT_WG);
-		dim3 rgrid((uint32_t)rblocks);
-#define MRT_LAUNCH_ROWS(A, C, N) hipLaunchKernelGGL((trace_packet_rows_kernel<A, C, N>), rgrid, wg, p.extra_lds, stream, p)
-		if (packets == 2u) {
-			if (count) { if (any_hit) MRT_LAUNCH_ROWS(true, true, 2); else MRT_LAUNCH_ROWS(false, true, 2); }
-			else { if (any_hit) MRT_LAUNCH_ROWS(true, false, 2); else MRT_LAUNCH_ROWS(false, false, 2); }
+		const uint32_t rows_wg = packets == 2u && p.rows_wg == 64u ? 64u : (uint32_t)MRT_WG;
+		const uint64_t rblocks = (threads + packets * rows_wg - 1) / (packets * rows_wg);
+		dim3 rgrid((uint32_t)rblocks), rwg(rows_wg);
+#define MRT_LAUNCH_ROWS(A, C, N, W) hipLaunchKernelGGL((trace_packet_rows_kernel<A, C, N, W>), rgrid, rwg, p.extra_lds, stream, p)
+		if (packets == 2u && rows_wg == 64u) {
+			if (count) { if (any_hit) MRT_LAUNCH_ROWS(true, true, 2, 64); else MRT_LAUNCH_ROWS(false, true, 2, 64); }
+			else { if (any_hit) MRT_LAUNCH_ROWS(true, false, 2, 64); else MRT_LAUNCH_ROWS(false, false, 2, 64); }
+		} else if (packets == 2u) {
+			if (count) { if (any_hit) MRT_LAUNCH_ROWS(true, true, 2, MRT_WG); else MRT_LAUNCH_ROWS(false, true, 2, MRT_WG); }
+			else { if (any_hit) MRT_LAUNCH_ROWS(true, false, 2, MRT_WG); else MRT_LAUNCH_ROWS(false, false, 2, MRT_WG); }
 		} else {
-			if (count) { if (any_hit) MRT_LAUNCH_ROWS(true, true, 1); else MRT_LAUNCH_ROWS(false, true, 1); }
-			else { if (any_hit) MRT_LAUNCH_ROWS(true, false, 1); else MRT_LAUNCH_ROWS(false, false, 1); }
+			if (count) { if (any_hit) MRT_LAUNCH_ROWS(true, true, 1, MRT_WG); else MRT_LAUNCH_ROWS(false, true, 1, MRT_WG); }
+			else { if (any_hit) MRT_LAUNCH_ROWS(true, false, 1, MRT_WG); else MRT_LAUNCH_ROWS(false, false, 1, MRT_WG); }
 		}
 #undef MRT_LAUNCH_ROWS
 		return hipGetLastError();

@@ -87,8 +87,7 @@ constexpr int kNumCounters = 16;
 constexpr int kAutoGridOff = kNumCounters;         // 8 words: what detect_grid_kernel found (4 x u32 used)
 constexpr int kDetectScratchOff = kAutoGridOff + 8; // 1026 words: jump masks + ticket + wide-neighbour count
 constexpr int kNextRayOff = kDetectScratchOff + 1026; // 128 words: 8 ray counters of the persistent kernels, 16 words apart
-constexpr int kPacketWorkOff = kNextRayOff + 128; // 32 words: work counter of the packet kernels (packet_rows_kernel.h)
-constexpr int kCounterWords = kPacketWorkOff + 32;
+constexpr int kCounterWords = kNextRayOff + 128;
 
 constexpr uint32_t kSentinel = 0x7FFFFFFFu;
 constexpr uint32_t kLeafBit = 0x80000000u;
@@ -111,8 +110,7 @@ struct TraceParams {
 	const TriCold *tri_cold;
 	const void *row_array;     // nodes + triangles as one array of 64-byte rows (packet_rows_kernel.h; may be null)
 	const void *row_array4;    // 4-wide node rows (128 bytes) + triangle rows, in 64-byte units (packet_quad_kernel.h; may be null)
-	unsigned long long *work_counter; // packet kernels, dynamic work distribution: {next item, -, ..., [16] waves that left}; null = static
-	uint32_t work_items;       // ... the number of wave work items of the launch
+	uint32_t rows_wg;          // trace_packet_rows_kernel<.., 2>: threads per workgroup, 64 or 256
 	uint32_t tri_unit_base4;   // row_array4: the unit of triangle slot 0 (= 2 * number of 4-wide nodes)
 	const void *rays;          // IN_RAY32 / IN_HOST60 (device)
 	void *hits;                // device

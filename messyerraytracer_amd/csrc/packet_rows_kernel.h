@@ -366,16 +366,14 @@ struct PacketRegs {
 
 // In: cur (group A's operand) = a row to visit, the groups' own masks.  Out: cur = 0x7FFFFFFF.
 // Stack entries are 32 bytes: {group A's mask, group B's mask, ref, -}; the sentinel entry has ref 0x7FFFFFFF.
-#define MRT_ROWS_LOOPW(CNT_N, CNT_T, CNT_P, T_PRE, T_POST, ANYA, ANYB, ANYDONE, BX, BY, BZ)                                                 \
+#define MRT_ROWS_LOOPW(CNT_N, CNT_T, CNT_P, ANYA, ANYB, ANYDONE, BX, BY, BZ)                                                 \
 	asm volatile(                                                                                                   \
 		"s_mov_b64 s[60:61], %[maskA]\n"                                                                            \
 		"s_mov_b64 s[62:63], %[maskB]\n"                                                                            \
 		"L_loop_%=:\n"                                                                                              \
 		"s_lshl_b32 s52, %[curA], 6\n"                                                                              \
-		T_PRE                                                                                                       \
 		"s_load_dwordx16 s[20:35], %[rows], s52\n"                                                                  \
 		"s_waitcnt lgkmcnt(0)\n"                                                                                    \
-		T_POST                                                                                                      \
 		"s_bitcmp1_b32 %[curA], 31\n"                                                                               \
 		"s_cbranch_scc1 L_tri_%=\n"                                                                                 \
 		CNT_N                                                                                                       \
@@ -451,11 +449,11 @@ struct PacketRegs {
 		"s_mov_b64 %[maskA], s[60:61]\n"                                                                            \
 		"s_mov_b64 %[maskB], s[62:63]\n"                                                                            \
 		: MRT_ROWS_OUT(A, a), [limB] "+v"(b.lim), [btB] "+v"(b.bt), [buB] "+v"(b.bu), [bvB] "+v"(b.bv),             \
-		  [bsB] "+v"(b.bs), [biB] "+v"(b.bi), [maskB] "+s"(b.mask), [cntn] "+s"(cnt_n), [cntt] "+s"(cnt_t), [cntp] "+s"(sp_max), [cntw] "+s"(cnt_w) \
+		  [bsB] "+v"(b.bs), [biB] "+v"(b.bi), [maskB] "+s"(b.mask), [cntn] "+s"(cnt_n), [cntt] "+s"(cnt_t), [cntp] "+s"(sp_max) \
 		: MRT_ROWS_IN(A, a), MRT_ROWS_IN(B, b), [rows] "s"(rows), [qmask] "s"(qmask), [eps] "s"(eps), [vneg] "v"(vneg) \
 		: MRT_ROWS_CLOBBERS)
 
-// counting builds also clock the row fetch: shader cycles from before the s_load to after
+// counting builds of the one-packet loop also clock the row fetch: shader cycles from before the s_load to after
 // its s_waitcnt (two s_memtime reads included), summed per wave in %[cntw]
 #define MRT_ROWS_T_PRE "s_memtime s[64:65]\n s_waitcnt lgkmcnt(0)\n"
 #define MRT_ROWS_T_POST "s_memtime s[66:67]\n s_waitcnt lgkmcnt(0)\n s_sub_u32 s64, s66, s64\n s_add_u32 %[cntw], %[cntw], s64\n"
@@ -491,20 +489,20 @@ __device__ __forceinline__ void rows_walk_one(const float4 *rows, uint32_t qmask
 }
 
 template <int OCT, bool ANY_HIT, bool COUNT>
-__device__ __forceinline__ void rows_walk_wide(const float4 *rows, uint32_t qmask, PacketRegs &a, PacketRegs &b, uint32_t &cnt_n, uint32_t &cnt_t, uint32_t &cnt_w, uint32_t &sp_max)
+__device__ __forceinline__ void rows_walk_wide(const float4 *rows, uint32_t qmask, PacketRegs &a, PacketRegs &b, uint32_t &cnt_n, uint32_t &cnt_t, uint32_t &sp_max)
 {
 	const float eps = 1e-8f, vneg = -FLT_MAX;
 #define MRT_WW(O, BX, BY, BZ)                                                                                         \
 	if (OCT == O) {                                                                                                 \
-		if (COUNT) { if (ANY_HIT) MRT_ROWS_LOOPW(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWS_CNT_P, MRT_ROWS_T_PRE, MRT_ROWS_T_POST, MRT_ROWSW_ANYHIT("A"), MRT_ROWSW_ANYHIT("B"), MRT_ROWSW_ANYDONE, BX, BY, BZ); \
-			else MRT_ROWS_LOOPW(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWS_CNT_P, MRT_ROWS_T_PRE, MRT_ROWS_T_POST, MRT_ROWS_NEAREST("A"), MRT_ROWS_NEAREST("B"), "", BX, BY, BZ); } \
-		else { if (ANY_HIT) MRT_ROWS_LOOPW("", "", "", "", "", MRT_ROWSW_ANYHIT("A"), MRT_ROWSW_ANYHIT("B"), MRT_ROWSW_ANYDONE, BX, BY, BZ); \
-			else MRT_ROWS_LOOPW("", "", "", "", "", MRT_ROWS_NEAREST("A"), MRT_ROWS_NEAREST("B"), "", BX, BY, BZ); }        \
+		if (COUNT) { if (ANY_HIT) MRT_ROWS_LOOPW(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWS_CNT_P, MRT_ROWSW_ANYHIT("A"), MRT_ROWSW_ANYHIT("B"), MRT_ROWSW_ANYDONE, BX, BY, BZ); \
+			else MRT_ROWS_LOOPW(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWS_CNT_P, MRT_ROWS_NEAREST("A"), MRT_ROWS_NEAREST("B"), "", BX, BY, BZ); } \
+		else { if (ANY_HIT) MRT_ROWS_LOOPW("", "", "", MRT_ROWSW_ANYHIT("A"), MRT_ROWSW_ANYHIT("B"), MRT_ROWSW_ANYDONE, BX, BY, BZ); \
+			else MRT_ROWS_LOOPW("", "", "", MRT_ROWS_NEAREST("A"), MRT_ROWS_NEAREST("B"), "", BX, BY, BZ); }        \
 	}
 	MRT_WW(0, 0, 0, 0) MRT_WW(1, 1, 0, 0) MRT_WW(2, 0, 1, 0) MRT_WW(3, 1, 1, 0) MRT_WW(4, 0, 0, 1) MRT_WW(5, 1, 0, 1) MRT_WW(6, 0, 1, 1) MRT_WW(7, 1, 1, 1)
 #undef MRT_WW
 	rows_uniform(a);
-	cnt_n = __builtin_amdgcn_readfirstlane(cnt_n); cnt_t = __builtin_amdgcn_readfirstlane(cnt_t); cnt_w = __builtin_amdgcn_readfirstlane(cnt_w);
+	cnt_n = __builtin_amdgcn_readfirstlane(cnt_n); cnt_t = __builtin_amdgcn_readfirstlane(cnt_t);
 	sp_max = __builtin_amdgcn_readfirstlane(sp_max);
 }
 
@@ -528,33 +526,18 @@ __device__ __forceinline__ int rows_octant(const RayRegs &r, bool part, unsigned
 	return uniform ? ((sx ? 1 : 0) | (sy ? 2 : 0) | (sz ? 4 : 0)) : 8;
 }
 
-// dynamic work distribution of the packet kernels: work_counter[0] = the next item, work_counter[16] (128 bytes on) =
-// waves that have left.  The last wave to leave zeroes both, so the next launch on the stream finds them ready.
-__device__ __forceinline__ uint32_t packet_next_item(const TraceParams &p, uint32_t lane)
-{
-	uint32_t t = 0u;
-	if (lane == 0u) t = (uint32_t)atomicAdd(p.work_counter, 1ull);
-	return __builtin_amdgcn_readfirstlane(t);
-}
-__device__ __forceinline__ void packet_items_done(const TraceParams &p, uint32_t lane)
-{
-	if (lane != 0u) return;
-	const unsigned long long left = atomicAdd(p.work_counter + 16, 1ull);
-	if (left + 1ull == (unsigned long long)gridDim.x * (MRT_WG / MRT_WAVE)) {
-		__hip_atomic_store(p.work_counter, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		__hip_atomic_store(p.work_counter + 16, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-	}
-}
-
 #ifndef MRT_ROWS_WPE
 #define MRT_ROWS_WPE 8
 #endif
 // PACKETS = 1: one packet per wave; 2: two (neighbouring tiles of the launch order).
-template <bool ANY_HIT, bool COUNT, int PACKETS>
-__global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS_WPE, 8))) void trace_packet_rows_kernel(const TraceParams p)
+// WG = threads per workgroup: 256 (four waves on neighbouring tiles share a CU and its scalar cache: C5 20.9 against
+// 22.6 ms) or 64 (a wave slot is refilled as soon as ITS wave ends, not when a workgroup's worth of slots is free:
+// C3 2.06 against 2.17 ms); api.hip picks by the size of the scene.
+template <bool ANY_HIT, bool COUNT, int PACKETS, int WG>
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS_WPE, 8))) void trace_packet_rows_kernel(const TraceParams p)
 {
 	// per wave and packet: 16-byte stack entries {ref, -, lane mask}; entry 0 holds the sentinel
-	__shared__ __attribute__((aligned(16))) uint32_t wave_stack[MRT_WG / MRT_WAVE][PACKETS][(MRT_PACKET_STACK + 1) * 4];
+	__shared__ __attribute__((aligned(16))) uint32_t wave_stack[WG / MRT_WAVE][PACKETS][(MRT_PACKET_STACK + 1) * 4];
 	if (skip_launch(p)) return;
 	uint32_t block = blockIdx.x;
 	if (p.xcd_swizzle) {
@@ -562,17 +545,7 @@ __global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS
 		if (block < (per << 3)) block = (block & 7u) * per + (block >> 3);
 	}
 	const uint32_t wave = threadIdx.x / MRT_WAVE, lane = threadIdx.x & (MRT_WAVE - 1);
-	// Work items (one per wave: PACKETS packets).  Static: item = the wave's position in the grid.  Dynamic
-	// (p.work_counter): resident waves draw items from a counter until none is left — packets differ 25-fold in
-	// cost (27 .. 667 rows at C3), and a grid of one-item waves leaves a quarter of the wave slots empty on average
-	// (5.7 of 8 waves per SIMD, profiles/r02d_*); the ticket of the NEXT item is drawn before the walk of this one.
-	const bool dynamic = p.work_counter != nullptr;
-	uint32_t item = block * (MRT_WG / MRT_WAVE) + wave;
-	if (dynamic) item = packet_next_item(p, lane);
-	for (;;) {
-	if (dynamic && item >= p.work_items) break;
-	const uint32_t next_item = dynamic ? packet_next_item(p, lane) : 0u;
-	const uint64_t g_a = ((uint64_t)item * PACKETS) * MRT_WAVE + lane, g_b = g_a + MRT_WAVE;
+	const uint64_t g_a = (((uint64_t)block * (WG / MRT_WAVE) + wave) * PACKETS) * MRT_WAVE + lane, g_b = g_a + MRT_WAVE;
 	uint64_t idx = 0; uint32_t px = 0, py = 0;
 	const bool valid_a = lane_ray_index_g(p, g_a, idx, px, py);
 	// a lane without a ray in a packet walks along with an empty interval
@@ -583,7 +556,7 @@ __global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS
 		valid_b = lane_ray_index_g(p, g_b, idx, px, py);
 		if (valid_b) load_ray(p, idx, px, py, rb);
 	}
-	if (__ballot(valid_a || valid_b) == 0ull) { if (!dynamic) return; item = next_item; continue; } // nothing for this wave (otherwise every lane stays in)
+	if (__ballot(valid_a || valid_b) == 0ull) return; // nothing for this wave (otherwise every lane stays in)
 
 	const float4 *rows = reinterpret_cast<const float4 *>(p.row_array);
 	uint32_t *stack_a = wave_stack[wave][0], *stack_b = wave_stack[wave][PACKETS - 1];
@@ -598,7 +571,7 @@ __global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS
 	const int oct_a = rows_octant(ra, valid_a, part_a);
 	const int oct_b = PACKETS == 2 ? rows_octant(rb, valid_b, part_b) : 8;
 	uint32_t cnt_n = 0u, cnt_t = 0u; // COUNT: node rows / triangle rows fetched by this wave
-	uint32_t cnt_w = 0u;             // COUNT: shader cycles between issuing a row fetch and having it
+	uint32_t cnt_w = 0u;             // COUNT, one-packet loop: shader cycles between issuing a row fetch and having it
 	uint32_t sp_wide = 0u, sp_one = 0u; // COUNT: highest stack pointers seen (LDS byte addresses) by the 128-ray / the one-packet walk
 	const unsigned long long t_start = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
 	bool done_a = part_a == 0ull, done_b = part_b == 0ull;
@@ -608,7 +581,7 @@ __global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS
 		*(volatile uint32_t *)&stack_a[4] = kSentinel;
 		A.sp += 16u; // (= stack base + 32)
 		A.mask = part_a; B.mask = part_b;
-#define MRT_RW2(O) case O: rows_walk_wide<O, ANY_HIT, COUNT>(rows, p.query_mask, A, B, cnt_n, cnt_t, cnt_w, sp_wide); break;
+#define MRT_RW2(O) case O: rows_walk_wide<O, ANY_HIT, COUNT>(rows, p.query_mask, A, B, cnt_n, cnt_t, sp_wide); break;
 		switch (oct_a) { MRT_RW2(0) MRT_RW2(1) MRT_RW2(2) MRT_RW2(3) MRT_RW2(4) MRT_RW2(5) MRT_RW2(6) MRT_RW2(7) }
 #undef MRT_RW2
 		done_a = done_b = true;
@@ -654,8 +627,4 @@ __global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS
 		if (valid_a) packet_count(p, cnt_n, cnt_t, 0u, slot_a != 0xFFFFFFFFu, part_a | part_b);
 		if (PACKETS == 2 && valid_b) { atomicAdd(&p.counters[kCntRays], 1ull); if (slot_b != 0xFFFFFFFFu) atomicAdd(&p.counters[kCntHits], 1ull); }
 	}
-	if (!dynamic) return;
-	item = next_item;
-	} // the next work item
-	packet_items_done(p, lane);
 }

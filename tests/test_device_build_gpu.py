@@ -47,7 +47,7 @@ def test_device_built_tree_gives_the_oracles_hits(built, n_tris, scale, seed):
 
 
 @pytest.mark.parametrize("kernel", [capi.KERNEL_LANE, capi.KERNEL_PACKET,
-                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
+                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, capi.KERNEL_PACKET_QUAD, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
                                     capi.KERNEL_LANE8_PERSISTENT])
 def test_every_kernel_walks_a_device_built_tree(built, kernel):
     """Kernels that want the 4-wide layout (absent for device-built trees) must fall back, not fault."""

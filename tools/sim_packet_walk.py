@@ -12,28 +12,47 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
-from messyerraytracer_amd import synth  # noqa: E402
-from oracle import pyoracle as po  # noqa: E402
+from messyerraytracer_amd import capi, synth  # noqa: E402
 
 LEAF = 0x80000000
 
 
 def build_tree(cfg):
-    v = synth.scene_vertices(cfg)
-    tris = po.make_triangles(v)
-    nodes, prim, used = po.bvh2_build(po.verts4(v))
-    wide, leaf_tris = po.to_wide(tris, nodes, prim)
-    return wide, leaf_tris
+    """the host builder's BVH2 (mrt_bvh2_build) as wide nodes: a node's row holds its two children's boxes"""
+    sc = capi.Scene(synth.scene_vertices(cfg))
+    nodes, prim = sc.nodes, sc.prim_idx
+    leaf_tris = sc.tris[prim]                      # leaf order
+    inner = np.nonzero(nodes["tri_count"] == 0)[0]
+    inner = inner[inner < sc.used_nodes]
+    # reachable inner nodes in index order (index 1 is the builder's unused slot)
+    wide_of = {int(n): i for i, n in enumerate(inner)}
+    return dict(nodes=nodes, wide_of=wide_of, inner=inner), leaf_tris
 
 
-def children2(wide, i):
-    w = wide[i]
+def children2(tree, i):
+    nodes = tree["nodes"]
+    n = nodes[tree["inner"][i]]
     out = []
-    for side in ("left", "right"):
-        cnt = int(w[side + "_count"])
-        idx = int(w[side + "_idx"])
-        out.append((np.concatenate([w[side + "_min"], w[side + "_max"]]), (LEAF | idx, cnt) if cnt else (idx, 0)))
+    for c in (int(n["left_first"]), int(n["left_first"]) + 1):
+        ch = nodes[c]
+        box = np.concatenate([ch["aabb_min"], ch["aabb_max"]])
+        cnt = int(ch["tri_count"])
+        out.append((box, (LEAF | int(ch["left_first"]), cnt) if cnt else (tree["wide_of"][c], 0)))
     return out
+
+
+def grid_rays(cfg, W, H, x0, y0, tw, th):
+    """the debug grid's pinhole rays of a tw x th tile (mrt_camera_look's basis; float32, planning accuracy)"""
+    cam = capi.camera_look(cfg["origin"], cfg["forward"], W, H, cfg["fov"])
+    fwd, right, up = (np.array(v[:], np.float32) for v in (cam.fwd, cam.right, cam.up))
+    xs = (np.arange(x0, x0 + tw, dtype=np.float32) + 0.5) / W * 2 - 1
+    ys = 1 - (np.arange(y0, y0 + th, dtype=np.float32) + 0.5) / H * 2
+    X, Y = np.meshgrid(xs, ys)
+    d = fwd[None, :] + (X.reshape(-1, 1) * cam.half_w) * right[None, :] + (Y.reshape(-1, 1) * cam.half_h) * up[None, :]
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    n = d.shape[0]
+    o = np.tile(np.array(cfg["origin"], np.float32), (n, 1))
+    return o, d.astype(np.float32), np.full(n, cam.t_min, np.float32), np.full(n, cam.t_max, np.float32)
 
 
 def collapse4(wide):
@@ -140,7 +159,7 @@ def main():
     a = ap.parse_args()
     cfg = synth.CONFIGS[a.config]
     wide, leaf_tris = build_tree(cfg)
-    print("tree built:", wide.shape[0], "wide nodes", flush=True)
+    print("tree built:", len(wide["inner"]), "wide nodes", flush=True)
     W, H = cfg["grid"]
     tw, th = (int(x) for x in a.tile.split("x"))
     rng = np.random.default_rng(5)
@@ -172,11 +191,7 @@ def main():
     for p in range(a.packets):
         tx0 = int(rng.integers(0, W // tw)) * tw
         ty0 = int(rng.integers(0, H // th)) * th
-        rows = po.grid_rays(cfg["origin"], cfg["forward"], W, H, cfg["fov"], y0=ty0, y1=ty0 + th)
-        rows = rows.reshape(th, W)[:, tx0:tx0 + tw].reshape(-1)
-        o = rows["origin"].astype(np.float32)
-        d = rows["direction"].astype(np.float32)
-        tmin, tmax = rows["t_min"].astype(np.float32), rows["t_max"].astype(np.float32)
+        o, d, tmin, tmax = grid_rays(cfg, W, H, tx0, ty0, tw, th)
         for name, get, order in (("bvh2", get2, "lane0"), ("bvh4_lane0", get4, "lane0"), ("bvh4_fixed", get4, "fixed")):
             s = walk(get, leaf_tris, o, d, tmin, tmax, order, grpA=(np.arange(tw * th) % tw) < tw // 2)
             for k in s:
