@@ -16,9 +16,24 @@
 // written straight into the layout the trace kernels read (mrt_internal.h).  One triangle per leaf.
 // The tree is a valid BVH over the same triangles, so by the tie rule ("Arithmetic")
 // casts against it return what casts against the host-built SAH tree return; it is a worse tree
-// (more node visits per ray), which is the price of building it in milliseconds.
+// (more node visits per ray), which is the price of building it in a few milliseconds.
+//
+// Steps 4-5 have two forms: the radix tree (the default) and, with MRT_BUILD_PLOC, PLOC — Meister and Bittner 2018, "Parallel Locally-
+// Ordered Clustering for Bounding Volume Hierarchy Construction": the Morton-sorted triangles are clusters on a
+// line; every round each cluster finds, among its 8 neighbours to either side, the one whose union with it
+// has the smallest surface area; clusters that choose each other merge into a node; a prefix sum compacts the
+// line; until one cluster is left.  It is agglomerative clustering restricted to the Morton neighbourhood: the
+// merges follow surface area instead of key bits, which is what the radix tree of step 4 cannot do.  About 30
+// rounds of four small launches per million triangles (2.9 against 1.2 ms).  Measured on the 1 M-triangle soup of
+// BASELINE config 3 (tools/bench_build.py, profiles/r02d_build_*): primary rays trace 1.05 x the host SAH tree's
+// time on the PLOC tree (radius 8; 1.07 at 16, 1.14 at 32, 1.16 at 64), 1.06-1.07 x on the radix tree; incoherent
+// rays 1.00 x against 0.93-0.94 x.  A uniform soup is the radix tree's best case (its cells are the cubes a SAH
+// builder would cut), so the radix tree stays the default and PLOC is there for scenes with structure.
+// Temporaries come from an arena the context owns (grown when a larger scene arrives, never shrunk): a rebuild
+// allocates nothing but the scene's own arrays.
 #include <cfloat>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string.h> // before rocprim: its texture_cache_iterator.hpp calls ::memset
 #include <hip/hip_runtime.h>
@@ -251,6 +266,108 @@ __global__ __launch_bounds__(LBVH_WG) void lbvh_verify_kernel(const DevNode *nod
 	if (!ok || mine != deepest + 1u) atomicAdd(bad, 1u);
 }
 
+// ---- PLOC (steps 4-5, quality form) ----------------------------------------------------------------------
+#define PLOC_R_MAX 64 // search radius on the line: positions to either side (run-time, <= this)
+
+__device__ __forceinline__ float ploc_union_area(const Box &a, const Box &b)
+{
+	const float ex = fmaxf(a.mx[0], b.mx[0]) - fminf(a.mn[0], b.mn[0]);
+	const float ey = fmaxf(a.mx[1], b.mx[1]) - fminf(a.mn[1], b.mn[1]);
+	const float ez = fmaxf(a.mx[2], b.mx[2]) - fminf(a.mn[2], b.mn[2]);
+	return ex * ey + ey * ez + ez * ex;
+}
+
+// the clusters of round 0: the sorted triangles
+__global__ __launch_bounds__(LBVH_WG) void ploc_init_kernel(const Box *tri_boxes, const uint32_t *sorted_tri, uint32_t n, Box *cbox, uint32_t *cref, uint32_t *cdepth)
+{
+	const uint32_t i = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (i >= n) return;
+	cbox[i] = tri_boxes[sorted_tri[i]]; cref[i] = kLeafBit | i; cdepth[i] = 0u;
+}
+
+// nearest neighbour on the line: the cluster within `radius` positions whose union with this one has the smallest
+// half-area.  Ties go to the smaller i ^ j — a key both ends of a pair compute alike, and smallest for the
+// neighbour that completes an even / odd pair, so a run of equal boxes pairs up completely in one round
+// instead of forming a chain with one mutual pair (300 coincident triangles: 9 rounds, not 299).
+__global__ __launch_bounds__(LBVH_WG) void ploc_nn_kernel(const Box *cbox, uint32_t m, int radius, uint32_t *nn)
+{
+	__shared__ Box sh[LBVH_WG + 2 * PLOC_R_MAX];
+	const int PLOC_R = radius;
+	const int64_t base = (int64_t)blockIdx.x * LBVH_WG - PLOC_R;
+	for (uint32_t t = threadIdx.x; t < (uint32_t)(LBVH_WG + 2 * PLOC_R); t += LBVH_WG) {
+		const int64_t g = base + t;
+		if (g >= 0 && g < (int64_t)m) sh[t] = cbox[g];
+	}
+	__syncthreads();
+	const uint32_t i = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (i >= m) return;
+	const Box b = sh[threadIdx.x + PLOC_R];
+	float best = FLT_MAX; uint32_t bj = i;
+	for (int d = -PLOC_R; d <= PLOC_R; d++) {
+		const int64_t j = (int64_t)i + d;
+		if (d == 0 || j < 0 || j >= (int64_t)m) continue;
+		const float a = ploc_union_area(b, sh[threadIdx.x + PLOC_R + d]);
+		if (a < best || (a == best && (i ^ (uint32_t)j) < (i ^ bj))) { best = a; bj = (uint32_t)j; }
+	}
+	nn[i] = bj;
+}
+
+// mutual nearest neighbours merge: the lower of the two stays (and becomes the node), the upper one leaves the line.
+// flags = keep | merged << 32, for one prefix sum of both
+__global__ __launch_bounds__(LBVH_WG) void ploc_flags_kernel(const uint32_t *nn, uint32_t m, unsigned long long *flags)
+{
+	const uint32_t i = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (i >= m) return;
+	const uint32_t j = nn[i];
+	const bool mutual = j != i && nn[j] == i;
+	const unsigned long long keep = (mutual && j < i) ? 0ull : 1ull, merged = (mutual && i < j) ? 1ull : 0ull;
+	flags[i] = keep | (merged << 32);
+}
+
+// the next line: survivors at their prefix position; a merged pair becomes node node_base + its merge rank
+// (creation order: children before parents, the root last) with both children's boxes in its row
+__global__ __launch_bounds__(LBVH_WG) void ploc_merge_kernel(const Box *cbox, const uint32_t *cref, const uint32_t *cdepth, const uint32_t *nn,
+		const unsigned long long *flags, const unsigned long long *pos, uint32_t m, uint32_t node_base,
+		Box *obox, uint32_t *oref, uint32_t *odepth, DevNode *staged, uint32_t *staged_depth, uint32_t *totals)
+{
+	const uint32_t i = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (i >= m) return;
+	const unsigned long long f = flags[i], p = pos[i];
+	if (i == m - 1u) { totals[0] = (uint32_t)(p + f); totals[1] = (uint32_t)((p + f) >> 32); } // survivors, merges of this round
+	if ((f & 1ull) == 0ull) return;
+	const uint32_t at = (uint32_t)p;
+	if ((f >> 32) == 0ull) { obox[at] = cbox[i]; oref[at] = cref[i]; odepth[at] = cdepth[i]; return; }
+	const uint32_t j = nn[i], id = node_base + (uint32_t)(p >> 32);
+	const Box lb = cbox[i], rb = cbox[j];
+	const uint32_t l = cref[i], r = cref[j], dl = cdepth[i], dr = cdepth[j];
+	DevNode g; Box u;
+	for (int k = 0; k < 3; k++) {
+		g.lmin[k] = lb.mn[k]; g.lmax[k] = lb.mx[k]; g.rmin[k] = rb.mn[k]; g.rmax[k] = rb.mx[k];
+		u.mn[k] = fminf(lb.mn[k], rb.mn[k]); u.mx[k] = fmaxf(lb.mx[k], rb.mx[k]);
+	}
+	g.left_ref = l; g.right_ref = r;
+	g.left_count = (l & kLeafBit) ? 1u : 0u; g.right_count = (r & kLeafBit) ? 1u : 0u;
+	staged[id] = g;
+	const uint32_t depth = (dl > dr ? dl : dr) + 1u;
+	staged_depth[id] = depth;
+	obox[at] = u; oref[at] = id; odepth[at] = depth;
+}
+
+// creation order -> root first: node id becomes n_nodes - 1 - id (the root, created last, is node 0)
+__global__ __launch_bounds__(LBVH_WG) void ploc_finish_kernel(const DevNode *staged, const uint32_t *staged_depth, uint32_t n_nodes,
+		DevNode *nodes, uint32_t *node_depth, uint32_t *max_depth)
+{
+	const uint32_t id = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (id >= n_nodes) return;
+	DevNode g = staged[id];
+	if (!(g.left_ref & kLeafBit)) g.left_ref = n_nodes - 1u - g.left_ref;
+	if (!(g.right_ref & kLeafBit)) g.right_ref = n_nodes - 1u - g.right_ref;
+	const uint32_t at = n_nodes - 1u - id;
+	nodes[at] = g;
+	node_depth[at] = staged_depth[id];
+	if (at == 0u) *max_depth = staged_depth[id];
+}
+
 // 5b. 4-wide collapse for the incoherent-ray kernel (one 128-byte line per step): the rule of
 //     scene_prep.cpp (start from a node's two children, keep opening the internal child with the
 //     largest half-area until there are four).  Every binary node gets the 4-wide node it WOULD be
@@ -480,14 +597,14 @@ hipError_t launch_flatten_instances(const float *d_verts9, const mrt_instance *d
 
 // Builds nodes / hot / cold (and nodes4 / nodes8 if wanted; hipMalloc'ed, owned by the caller on success) for
 // the n >= 2 triangles at d_tris (device).  depth = stack entries a traversal can need (incl. the sentinel).
-int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want8, bool safe_handoff, void *stream_, DeviceBuildResult *out, char *err, size_t err_len)
+// Temporaries are carved from *arena (grown here if it is too small; owned by the caller, kept between builds).
+int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want8, bool safe_handoff, bool fast_lbvh, BuildArena *arena, void *stream_,
+		DeviceBuildResult *out, char *err, size_t err_len)
 {
 	hipStream_t stream = (hipStream_t)stream_;
-	void *tmp[16] = {}; int n_tmp = 0;
 	DevNode *nodes = nullptr; TriHot *hot = nullptr; TriCold *cold = nullptr; Dev4Node *nodes4 = nullptr; Dev8Node *nodes8 = nullptr;
 	float *leaf_box = nullptr;
 	auto cleanup = [&] {
-		for (int i = 0; i < n_tmp; i++) if (tmp[i]) (void)hipFree(tmp[i]);
 		if (nodes) (void)hipFree(nodes);
 		if (nodes4) (void)hipFree(nodes4);
 		if (nodes8) (void)hipFree(nodes8);
@@ -495,23 +612,37 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 		if (hot) (void)hipFree(hot);
 		if (cold) (void)hipFree(cold);
 	};
-	auto alloc = [&](size_t bytes) -> void * {
-		void *p = nullptr;
-		if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) return nullptr;
-		tmp[n_tmp++] = p;
-		return p;
-	};
 	const size_t nn = n;
-	Box *boxes = (Box *)alloc(nn * sizeof(Box));
-	uint32_t *scal = (uint32_t *)alloc(16 * sizeof(uint32_t)); // bounds[6], max_depth, 8-wide "bad" flag, verification failures
-	uint64_t *keys_a = (uint64_t *)alloc(nn * 8), *keys_b = (uint64_t *)alloc(nn * 8);
-	uint32_t *idx_a = (uint32_t *)alloc(nn * 4), *idx_b = (uint32_t *)alloc(nn * 4);
-	uint32_t *left = (uint32_t *)alloc(nn * 4), *right = (uint32_t *)alloc(nn * 4);
-	uint32_t *par_node = (uint32_t *)alloc(nn * 4), *par_leaf = (uint32_t *)alloc(nn * 4);
-	uint32_t *arrivals = (uint32_t *)alloc(nn * 4), *node_depth = (uint32_t *)alloc(nn * 4);
-	Box *node_box = (Box *)alloc(nn * sizeof(Box));
-	bool ok = boxes && scal && keys_a && keys_b && idx_a && idx_b && left && right && par_node && par_leaf && arrivals && node_depth && node_box;
-	ok = ok && hipMalloc(&nodes, (nn - 1) * sizeof(DevNode)) == hipSuccess && hipMalloc(&hot, nn * sizeof(TriHot) + 16) == hipSuccess &&
+	// ---- the arena: one allocation, carved in 256-byte steps ----
+	size_t sort_bytes = 0, scan_bytes = 0;
+	DB_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr, nn, 0, 63, stream));
+	DB_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (unsigned long long *)nullptr, (unsigned long long *)nullptr, 0ull, nn, rocprim::plus<unsigned long long>(), stream));
+	size_t need = 0;
+	auto reserve = [&](size_t bytes) { const size_t at = need; need += (bytes + 255u) & ~(size_t)255u; return at; };
+	const size_t o_boxes = reserve(nn * sizeof(Box)), o_scal = reserve(64), o_keys_a = reserve(nn * 8), o_keys_b = reserve(nn * 8),
+			o_idx_a = reserve(nn * 4), o_idx_b = reserve(nn * 4), o_depth = reserve(nn * 4), o_sort = reserve(sort_bytes > scan_bytes ? sort_bytes : scan_bytes);
+	// radix-tree form: left / right / parents / arrivals / node boxes; PLOC form: two cluster lines, nn, flags, positions, staged rows
+	const size_t o_left = reserve(nn * 4), o_right = reserve(nn * 4), o_par_node = reserve(nn * 4), o_par_leaf = reserve(nn * 4),
+			o_arrivals = reserve(nn * 4), o_node_box = reserve(nn * sizeof(Box));
+	const size_t lbvh_end = need;
+	need = o_left; // the two forms never run together: their temporaries share the space
+	const size_t o_cbox0 = reserve(nn * sizeof(Box)), o_cbox1 = reserve(nn * sizeof(Box)), o_cref0 = reserve(nn * 4), o_cref1 = reserve(nn * 4),
+			o_cdep0 = reserve(nn * 4), o_cdep1 = reserve(nn * 4), o_nn = reserve(nn * 4), o_flags = reserve(nn * 8), o_pos = reserve(nn * 8),
+			o_staged = reserve(nn * sizeof(DevNode)), o_sdepth = reserve(nn * 4);
+	if (need < lbvh_end) need = lbvh_end;
+	if (arena->cap < need) {
+		if (arena->ptr) { DB_TRY(hipStreamSynchronize(stream)); (void)hipFree(arena->ptr); arena->ptr = nullptr; arena->cap = 0; }
+		if (hipMalloc(&arena->ptr, need) != hipSuccess) { arena->ptr = nullptr; std::snprintf(err, err_len, "device build: out of device memory"); return MRT_ERR_OOM; }
+		arena->cap = need;
+	}
+	char *A = (char *)arena->ptr;
+	Box *boxes = (Box *)(A + o_boxes);
+	uint32_t *scal = (uint32_t *)(A + o_scal); // bounds[6], max_depth, 8-wide "bad" flag, verification failures, [10..11] PLOC round totals
+	uint64_t *keys_a = (uint64_t *)(A + o_keys_a), *keys_b = (uint64_t *)(A + o_keys_b);
+	uint32_t *idx_a = (uint32_t *)(A + o_idx_a), *idx_b = (uint32_t *)(A + o_idx_b);
+	uint32_t *node_depth = (uint32_t *)(A + o_depth);
+	void *sort_tmp = A + o_sort;
+	bool ok = hipMalloc(&nodes, (nn - 1) * sizeof(DevNode)) == hipSuccess && hipMalloc(&hot, nn * sizeof(TriHot) + 16) == hipSuccess &&
 			hipMalloc(&cold, nn * sizeof(TriCold)) == hipSuccess &&
 			(!want4 || hipMalloc(&nodes4, (nn - 1) * sizeof(Dev4Node)) == hipSuccess) &&
 			(!want8 || (hipMalloc(&nodes8, (nn - 1) * sizeof(Dev8Node)) == hipSuccess && hipMalloc(&leaf_box, nn * 32) == hipSuccess));
@@ -520,40 +651,76 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 	const uint32_t blocks = (uint32_t)((nn + LBVH_WG - 1) / LBVH_WG);
 	const uint32_t init[16] = { 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u };
 	DB_TRY(hipMemcpyAsync(scal, init, sizeof(init), hipMemcpyHostToDevice, stream));
-	DB_TRY(hipMemsetAsync(arrivals, 0, nn * 4, stream));
 	hipLaunchKernelGGL(lbvh_bounds_kernel, dim3(blocks < LBVH_BOUNDS_BLOCKS ? blocks : LBVH_BOUNDS_BLOCKS), dim3(LBVH_WG), 0, stream,
 			d_tris, n, boxes, scal);
 	hipLaunchKernelGGL(lbvh_keys_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, boxes, n, scal, keys_a, idx_a);
-	size_t sort_bytes = 0;
-	DB_TRY(rocprim::radix_sort_pairs(nullptr, sort_bytes, keys_a, keys_b, idx_a, idx_b, nn, 0, 63, stream));
-	void *sort_tmp = alloc(sort_bytes);
-	if (!sort_tmp) { std::snprintf(err, err_len, "device build: out of device memory"); cleanup(); return MRT_ERR_OOM; }
 	DB_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys_a, keys_b, idx_a, idx_b, nn, 0, 63, stream));
-	hipLaunchKernelGGL(lbvh_hierarchy_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, keys_b, n, left, right, par_node, par_leaf);
 	hipLaunchKernelGGL(lbvh_leaves_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, d_tris, n, idx_b, hot, cold);
 	uint32_t h[16];
-	// attempt 0: write-through hand-off; attempt 1: acquire-release hand-off, if the verification failed (or asked for)
-	for (int attempt = safe_handoff ? 1 : 0;; attempt++) {
-		if (attempt == 0)
-			hipLaunchKernelGGL(lbvh_fit_kernel<false>, dim3(blocks), dim3(LBVH_WG), 0, stream, n, boxes, idx_b, left, right, par_node, par_leaf,
-					arrivals, node_box, node_depth, nodes, scal + 6);
-		else {
-			DB_TRY(hipMemsetAsync(arrivals, 0, nn * 4, stream));
-			DB_TRY(hipMemsetAsync(scal + 6, 0, 3 * sizeof(uint32_t), stream));
-			hipLaunchKernelGGL(lbvh_fit_kernel<true>, dim3(blocks), dim3(LBVH_WG), 0, stream, n, boxes, idx_b, left, right, par_node, par_leaf,
-					arrivals, node_box, node_depth, nodes, scal + 6);
+	if (!fast_lbvh) {
+		// ---- PLOC: rounds of nearest neighbour / flags / prefix sum / merge on the line of clusters ----
+		Box *cbox[2] = { (Box *)(A + o_cbox0), (Box *)(A + o_cbox1) };
+		uint32_t *cref[2] = { (uint32_t *)(A + o_cref0), (uint32_t *)(A + o_cref1) }, *cdep[2] = { (uint32_t *)(A + o_cdep0), (uint32_t *)(A + o_cdep1) };
+		uint32_t *nnb = (uint32_t *)(A + o_nn);
+		unsigned long long *flags = (unsigned long long *)(A + o_flags), *pos = (unsigned long long *)(A + o_pos);
+		DevNode *staged = (DevNode *)(A + o_staged);
+		uint32_t *sdepth = (uint32_t *)(A + o_sdepth);
+		hipLaunchKernelGGL(ploc_init_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, boxes, idx_b, n, cbox[0], cref[0], cdep[0]);
+		uint32_t m = n, node_base = 0u;
+		int cur = 0;
+		int ploc_radius = 8;
+		if (const char *e = std::getenv("MRT_PLOC_RADIUS")) { const int r = std::atoi(e); if (r >= 1 && r <= PLOC_R_MAX) ploc_radius = r; } // tuning knob (tools/bench_build.py)
+		for (uint32_t round = 0; m > 1u; round++) {
+			if (round > 4096u) { std::snprintf(err, err_len, "device build: clustering did not converge"); cleanup(); return MRT_ERR_HIP; }
+			const uint32_t mb = (m + LBVH_WG - 1) / LBVH_WG;
+			hipLaunchKernelGGL(ploc_nn_kernel, dim3(mb), dim3(LBVH_WG), 0, stream, cbox[cur], m, ploc_radius, nnb);
+			hipLaunchKernelGGL(ploc_flags_kernel, dim3(mb), dim3(LBVH_WG), 0, stream, nnb, m, flags);
+			DB_TRY(rocprim::exclusive_scan(sort_tmp, scan_bytes, flags, pos, 0ull, (size_t)m, rocprim::plus<unsigned long long>(), stream));
+			hipLaunchKernelGGL(ploc_merge_kernel, dim3(mb), dim3(LBVH_WG), 0, stream, cbox[cur], cref[cur], cdep[cur], nnb, flags, pos, m, node_base,
+					cbox[cur ^ 1], cref[cur ^ 1], cdep[cur ^ 1], staged, sdepth, scal + 10);
+			uint32_t totals[2];
+			DB_TRY(hipMemcpyAsync(totals, scal + 10, sizeof(totals), hipMemcpyDeviceToHost, stream));
+			DB_TRY(hipStreamSynchronize(stream));
+			if (totals[1] == 0u || totals[0] + totals[1] != m) { std::snprintf(err, err_len, "device build: a clustering round made no progress"); cleanup(); return MRT_ERR_HIP; }
+			m = totals[0]; node_base += totals[1];
+			cur ^= 1;
 		}
+		if (node_base != n - 1u) { std::snprintf(err, err_len, "device build: clustering produced %u nodes for %u triangles", node_base, n); cleanup(); return MRT_ERR_HIP; }
+		hipLaunchKernelGGL(ploc_finish_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, staged, sdepth, n - 1, nodes, node_depth, scal + 6);
 		hipLaunchKernelGGL(lbvh_verify_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, boxes, idx_b, node_depth, scal + 6, scal + 8);
 		if (want4) hipLaunchKernelGGL(lbvh_collapse4_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes4);
 		if (want8) hipLaunchKernelGGL(lbvh_collapse8_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes8, leaf_box, scal + 7);
 		DB_TRY(hipGetLastError());
 		DB_TRY(hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, stream));
 		DB_TRY(hipStreamSynchronize(stream));
-		if (h[8] == 0u) break;
-		if (attempt >= 1) { std::snprintf(err, err_len, "device build: the tree failed its verification pass (%u nodes)", h[8]); cleanup(); return MRT_ERR_HIP; }
+		if (h[8] != 0u) { std::snprintf(err, err_len, "device build: the tree failed its verification pass (%u nodes)", h[8]); cleanup(); return MRT_ERR_HIP; }
+	} else {
+		uint32_t *left = (uint32_t *)(A + o_left), *right = (uint32_t *)(A + o_right), *par_node = (uint32_t *)(A + o_par_node), *par_leaf = (uint32_t *)(A + o_par_leaf);
+		uint32_t *arrivals = (uint32_t *)(A + o_arrivals);
+		Box *node_box = (Box *)(A + o_node_box);
+		DB_TRY(hipMemsetAsync(arrivals, 0, nn * 4, stream));
+		hipLaunchKernelGGL(lbvh_hierarchy_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, keys_b, n, left, right, par_node, par_leaf);
+		// attempt 0: write-through hand-off; attempt 1: acquire-release hand-off, if the verification failed (or asked for)
+		for (int attempt = safe_handoff ? 1 : 0;; attempt++) {
+			if (attempt == 0)
+				hipLaunchKernelGGL(lbvh_fit_kernel<false>, dim3(blocks), dim3(LBVH_WG), 0, stream, n, boxes, idx_b, left, right, par_node, par_leaf,
+						arrivals, node_box, node_depth, nodes, scal + 6);
+			else {
+				DB_TRY(hipMemsetAsync(arrivals, 0, nn * 4, stream));
+				DB_TRY(hipMemsetAsync(scal + 6, 0, 3 * sizeof(uint32_t), stream));
+				hipLaunchKernelGGL(lbvh_fit_kernel<true>, dim3(blocks), dim3(LBVH_WG), 0, stream, n, boxes, idx_b, left, right, par_node, par_leaf,
+						arrivals, node_box, node_depth, nodes, scal + 6);
+			}
+			hipLaunchKernelGGL(lbvh_verify_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, boxes, idx_b, node_depth, scal + 6, scal + 8);
+			if (want4) hipLaunchKernelGGL(lbvh_collapse4_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes4);
+			if (want8) hipLaunchKernelGGL(lbvh_collapse8_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, nodes, n - 1, nodes8, leaf_box, scal + 7);
+			DB_TRY(hipGetLastError());
+			DB_TRY(hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, stream));
+			DB_TRY(hipStreamSynchronize(stream));
+			if (h[8] == 0u) break;
+			if (attempt >= 1) { std::snprintf(err, err_len, "device build: the tree failed its verification pass (%u nodes)", h[8]); cleanup(); return MRT_ERR_HIP; }
+		}
 	}
-	for (int i = 0; i < n_tmp; i++) (void)hipFree(tmp[i]);
-	n_tmp = 0;
 	out->nodes = nodes; out->hot = hot; out->cold = cold;
 	out->n_nodes = n - 1; out->n_tris = n;
 	out->depth = h[6] + 1u; // pending entries on the deepest path + the sentinel

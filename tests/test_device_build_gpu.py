@@ -34,13 +34,14 @@ def _check(c, osc, name, masks=(0xFFFFFFFF,)):
     parity.assert_exact(c.cast_grid(cam, 100, 70), osc.trace(grid), f"{name} cast_grid")
 
 
-@pytest.mark.parametrize("n_tris,scale,seed", [(1, 2.0, 5), (2, 2.0, 6), (3, 1.5, 7), (17, 1.0, 8), (1000, 0.5, 1), (20000, 0.25, 33)])
-def test_device_built_tree_gives_the_oracles_hits(built, n_tris, scale, seed):
+@pytest.mark.parametrize("ploc", [False, True], ids=["radix_tree", "ploc"])
+@pytest.mark.parametrize("n_tris,scale,seed", [(1, 2.0, 5), (2, 2.0, 6), (3, 1.5, 7), (17, 1.0, 8), (33, 1.0, 18), (1000, 0.5, 1), (20000, 0.25, 33)])
+def test_device_built_tree_gives_the_oracles_hits(built, n_tris, scale, seed, ploc):
     v = synth.soup(n_tris, scale, seed)
     layers = (1 << (np.arange(n_tris) % 3)).astype(np.uint32)
     tris = capi.make_triangles(v, None, layers)
     c = capi.Context(0)
-    c.build_scene_device(tris)
+    c.build_scene_device(tris, ploc=ploc)
     assert c.is_available() and c.scene_info()["n_tris"] == n_tris
     _check(c, po.OracleScene(v, None, layers), f"n={n_tris}", masks=(0xFFFFFFFF, 0x5))
     c.close()
@@ -58,15 +59,16 @@ def test_every_kernel_walks_a_device_built_tree(built, kernel):
     c.close()
 
 
-def test_degenerate_inputs_for_the_radix_tree(built):
-    """Equal Morton keys (coincident triangles, a flat cluster with one outlier) are split by index;
-    the tree stays a valid BVH of bounded depth."""
+@pytest.mark.parametrize("ploc", [False, True], ids=["radix_tree", "ploc"])
+def test_degenerate_inputs_for_the_device_builders(built, ploc):
+    """Equal Morton keys (coincident triangles, a flat cluster with one outlier): the radix tree splits them by
+    index, the clustering merges boxes of equal area by position; the tree stays a valid BVH of bounded depth."""
     base = synth.soup(1, 0.5, 3)
     same = np.repeat(base, 300, axis=0)                       # 300 copies of one triangle: all keys equal
     v = np.concatenate([same, synth.soup(50, 0.2, 4) * 0.001, synth.soup(1, 0.5, 9) + 4.0]).astype(np.float32)
     ids = np.arange(v.shape[0], dtype=np.uint32)[::-1].copy()  # the winner among exact ties is the LOWEST id
     c = capi.Context(0)
-    c.build_scene_device(capi.make_triangles(v, ids))
+    c.build_scene_device(capi.make_triangles(v, ids), ploc=ploc)
     _check(c, po.OracleScene(v, ids), "degenerate")
     assert c.scene_info()["stack_need"] <= 64
     c.close()
@@ -93,6 +95,10 @@ def test_device_resident_triangles_and_rebuild(built):
     # the acquire-release hand-off (what a build falls back to if its verification pass fails)
     c.build_scene_device(capi.make_triangles(v), safe_handoff=True)
     _check(c, po.OracleScene(v), "safe hand-off")
+    c.build_scene_device(capi.make_triangles(v), ploc=True)      # clustering after the radix tree and back: one arena serves both
+    _check(c, po.OracleScene(v), "clustering after the radix tree")
+    c.build_scene_device(capi.make_triangles(v))
+    _check(c, po.OracleScene(v), "radix tree after clustering")
     with pytest.raises(capi.MrtError):
         c.build_scene_device(np.zeros(0, dtype=T.TRI64))
     c.close()

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build time and trace time: host-built 8-bin SAH tree (mrt_bvh2_build + mrt_upload_scene) against
-the device-built LBVH (mrt_build_scene_device), on one config's scene and primary-ray grid.
+the device-built trees (mrt_build_scene_device: the radix tree, and PLOC with MRT_BUILD_PLOC), on one config's scene and primary-ray grid.
 
     python tools/bench_build.py --config C3 [--rounds 5]
 """
@@ -67,22 +67,29 @@ def main():
                        stack_need=ctx.scene_info()["stack_need"], trace_ms=trace_ms(), incoherent_4M_ms=incoherent_ms())
     host_hits = digest()
 
-    # device: triangles from host memory (PCIe included in wall time), and already resident
-    walls, devs = [], []
-    for _ in range(a.rounds):
-        t0 = time.perf_counter()
-        ctx.build_scene_device(tris)
-        walls.append(time.perf_counter() - t0)
-        devs.append(ctx.stats()["last_build_ms"])
+    # device: triangles from host memory (PCIe included in wall time), and already resident; the default form
+    # (the radix tree) and locally-ordered clustering (MRT_BUILD_PLOC)
     d_tris = ctx.device_alloc(tris.nbytes)
     ctx.h2d(d_tris, tris)
-    res = []
-    for _ in range(a.rounds):
-        ctx.build_scene_device(d_tris, n_tris=n, on_device=True)
-        res.append(ctx.stats()["last_build_ms"])
-    out["device"] = dict(build_ms_from_host_tris=float(np.median(devs)), wall_ms_from_host_tris=float(np.median(walls)) * 1e3,
+    for name, ploc in (("device", False), ("device_ploc", True)):
+        walls, devs = [], []
+        for _ in range(a.rounds):
+            t0 = time.perf_counter()
+            ctx.build_scene_device(tris, ploc=ploc)
+            walls.append(time.perf_counter() - t0)
+            devs.append(ctx.stats()["last_build_ms"])
+        res = []
+        for _ in range(a.rounds):
+            ctx.build_scene_device(d_tris, n_tris=n, on_device=True, ploc=ploc)
+            res.append(ctx.stats()["last_build_ms"])
+        out[name] = dict(build_ms_from_host_tris=float(np.median(devs)), wall_ms_from_host_tris=float(np.median(walls)) * 1e3,
                          build_ms_resident_tris=float(np.median(res)), stack_need=ctx.scene_info()["stack_need"], trace_ms=trace_ms(),
                          incoherent_4M_ms=incoherent_ms())
+        out[name]["identical_hits"] = bool(digest().tobytes() == host_hits.tobytes())
+        out[name]["trace_vs_host"] = out[name]["trace_ms"] / out["host"]["trace_ms"]
+        out[name]["incoherent_vs_host"] = out[name]["incoherent_4M_ms"] / out["host"]["incoherent_4M_ms"]
+    ctx.build_scene_device(d_tris, n_tris=n, on_device=True)
+    ctx.cast_grid(cam, w, h, hits=d_hits, flags=capi.FLAG_HITS_ON_DEVICE)
     out["identical_hits"] = bool(digest().tobytes() == host_hits.tobytes())
     if cfg.get("scene") == "multi_mesh":
         # the same scene as placed meshes: flatten (Transform3D::xform + Triangle ctor) and build on the device
