@@ -169,6 +169,9 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 	if (ctx->opts.tile_order == 3) p.tile_order = 2u; // 32x32-tile super-tiles (C5: 23.3 against 23.5 ms; not the default)
 	p.extra_lds = ctx->opts.extra_lds <= 60000u ? ctx->opts.extra_lds : 60000u;
 	p.count_mode = ctx->opts.count_visits;
+	p.rows_cull = ctx->opts.packet_cull == 2u ? 1u : 0u; // off by default: the test's vector loads cost more than the skipped slab tests save (packet_rows_kernel.h)
+	p.scene_abs_max = 0.0f;
+	for (int c = 0; c < 3; c++) p.scene_abs_max = std::fmax(p.scene_abs_max, std::fmax(std::fabs(ctx->bounds_lo[c]), std::fabs(ctx->bounds_hi[c])));
 	p.rows_wg = ctx->opts.packet_wg == 64u || ctx->opts.packet_wg == 256u ? ctx->opts.packet_wg : (scene_bytes > (size_t)256 << 20 ? 256u : 64u);
 	p.kernel = MRT_KERNEL_LANE; // callers pick per batch with pick_kernel()
 }
@@ -521,7 +524,7 @@ int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
 	if (!out) return MRT_ERR_INVALID;
 	*out = nullptr;
 	if (opts && opts->struct_size != sizeof(mrt_options)) return MRT_ERR_INVALID;
-	if (opts && ((opts->packet_wg != 0u && opts->packet_wg != 64u && opts->packet_wg != 256u) || opts->kernel > MRT_KERNEL_PACKET_QUAD || opts->kernel == 3u || opts->kernel == 4u)) return MRT_ERR_INVALID; // 3, 4: retired ids
+	if (opts && ((opts->packet_wg != 0u && opts->packet_wg != 64u && opts->packet_wg != 256u) || opts->packet_cull > 2u || opts->kernel > MRT_KERNEL_PACKET_QUAD || opts->kernel == 3u || opts->kernel == 4u)) return MRT_ERR_INVALID; // 3, 4: retired ids
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || device_ordinal < 0 || device_ordinal >= n) return MRT_ERR_NO_DEVICE;
 	mrt_ctx *ctx = new (std::nothrow) mrt_ctx();

@@ -697,17 +697,17 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		const uint32_t rows_wg = packets == 2u && p.rows_wg == 64u ? 64u : (uint32_t)MRT_WG;
 		const uint64_t rblocks = (threads + packets * rows_wg - 1) / (packets * rows_wg);
 		dim3 rgrid((uint32_t)rblocks), rwg(rows_wg);
-#define MRT_LAUNCH_ROWS(A, C, N, W) hipLaunchKernelGGL((trace_packet_rows_kernel<A, C, N, W>), rgrid, rwg, p.extra_lds, stream, p)
-		if (packets == 2u && rows_wg == 64u) {
-			if (count) { if (any_hit) MRT_LAUNCH_ROWS(true, true, 2, 64); else MRT_LAUNCH_ROWS(false, true, 2, 64); }
-			else { if (any_hit) MRT_LAUNCH_ROWS(true, false, 2, 64); else MRT_LAUNCH_ROWS(false, false, 2, 64); }
-		} else if (packets == 2u) {
-			if (count) { if (any_hit) MRT_LAUNCH_ROWS(true, true, 2, MRT_WG); else MRT_LAUNCH_ROWS(false, true, 2, MRT_WG); }
-			else { if (any_hit) MRT_LAUNCH_ROWS(true, false, 2, MRT_WG); else MRT_LAUNCH_ROWS(false, false, 2, MRT_WG); }
-		} else {
-			if (count) { if (any_hit) MRT_LAUNCH_ROWS(true, true, 1, MRT_WG); else MRT_LAUNCH_ROWS(false, true, 1, MRT_WG); }
-			else { if (any_hit) MRT_LAUNCH_ROWS(true, false, 1, MRT_WG); else MRT_LAUNCH_ROWS(false, false, 1, MRT_WG); }
-		}
+#define MRT_LAUNCH_ROWS(A, C, N, W, F) hipLaunchKernelGGL((trace_packet_rows_kernel<A, C, N, W, F>), rgrid, rwg, p.extra_lds, stream, p)
+#define MRT_LAUNCH_ROWS_AC(N, W, F)                                                                                    \
+		do {                                                                                                        \
+			if (count) { if (any_hit) MRT_LAUNCH_ROWS(true, true, N, W, F); else MRT_LAUNCH_ROWS(false, true, N, W, F); } \
+			else { if (any_hit) MRT_LAUNCH_ROWS(true, false, N, W, F); else MRT_LAUNCH_ROWS(false, false, N, W, F); }   \
+		} while (0)
+		const bool cull = packets == 2u && p.rows_cull != 0u;
+		if (packets == 2u && rows_wg == 64u) { if (cull) MRT_LAUNCH_ROWS_AC(2, 64, true); else MRT_LAUNCH_ROWS_AC(2, 64, false); }
+		else if (packets == 2u) { if (cull) MRT_LAUNCH_ROWS_AC(2, MRT_WG, true); else MRT_LAUNCH_ROWS_AC(2, MRT_WG, false); }
+		else MRT_LAUNCH_ROWS_AC(1, MRT_WG, false);
+#undef MRT_LAUNCH_ROWS_AC
 #undef MRT_LAUNCH_ROWS
 		return hipGetLastError();
 	}

@@ -111,6 +111,8 @@ struct TraceParams {
 	const void *row_array;     // nodes + triangles as one array of 64-byte rows (packet_rows_kernel.h; may be null)
 	const void *row_array4;    // 4-wide node rows (128 bytes) + triangle rows, in 64-byte units (packet_quad_kernel.h; may be null)
 	uint32_t rows_wg;          // trace_packet_rows_kernel<.., 2>: threads per workgroup, 64 or 256
+	uint32_t rows_cull;        // ... 1: packet-level frustum culling in the 128-ray walk
+	float scene_abs_max;       // largest |coordinate| of the scene's bounds (error bound of the culling test)
 	uint32_t tri_unit_base4;   // row_array4: the unit of triangle slot 0 (= 2 * number of 4-wide nodes)
 	const void *rays;          // IN_RAY32 / IN_HOST60 (device)
 	void *hits;                // device

@@ -453,6 +453,167 @@ struct PacketRegs {
 		: MRT_ROWS_IN(A, a), MRT_ROWS_IN(B, b), [rows] "s"(rows), [qmask] "s"(qmask), [eps] "s"(eps), [vneg] "v"(vneg) \
 		: MRT_ROWS_CLOBBERS)
 
+
+// ---- the 128-ray walk with packet-level frustum culling (round 2, after the walk was found vector-issue bound) -----
+// 46 % of the (group, child box) slab tests of a C3 packet fail for all 64 rays of the group (47 % at C5), and 92-97 %
+// of those boxes lie wholly outside the pyramid the packet's rays span: the packet can skip a child's 22 per-ray
+// instructions after a test that costs 10, done by eight lanes at once.
+// MEASURED (profiles/r02d_frustum_cull.txt): vector instructions per wave 10 388 -> 9 109 at C3, results identical,
+// and the kernel 8 % SLOWER (C3 1.99 -> 2.15 ms, C5 21.1 -> 23.2 ms): the lanes get their box corners by vector loads,
+// whose latency (SQ_WAIT_ANY 106 -> 183 thousand cycles per wave) eight waves no longer hide.  Every other way to put
+// three of the row's twelve coordinates into eight different lanes costs more vector instructions than the skipped
+// tests save.  Kept behind mrt_options.packet_cull = 2 (off by default), held to the oracle by the packet tests.
+// Lane l < 8 stands for (child b = l >> 2, side plane k = l & 3) of the packet's pyramid (apex = the common ray origin,
+// planes through the corner rays, pushed outwards): it loads the three coordinates of the box's corner that lies
+// farthest along the plane's inward normal n' (a per-lane byte offset into the row each), forms dot(n', corner) and
+// compares it with cc = dot(n', apex) - eps.  Smaller: the whole box is outside that plane, no ray of the packet
+// reaches it, both groups' tests of that child are skipped (masks zero).  See cull_setup() for n', eps and the
+// conditions under which a packet culls at all (else cc = -inf and nothing is ever skipped).
+// One child box against one group (the arithmetic of MRT_ROWS_SLAB, one box at a time): TE = entry distance
+// (v50 for the left child, v56 for the right one: what the near / far decision reads), MASK = lanes that hit
+#define MRT_ROWS_SLAB1(P, RS, SIDE, TE, BX, BY, BZ, MASK)                                                             \
+	"v_fma_f32 v51, " MRT_NEAR_##BX(RS, X, SIDE) ", " MRT_OP("ix", P) ", " MRT_OP("nrx", P) "\n"                      \
+	"v_fma_f32 v52, " MRT_NEAR_##BY(RS, Y, SIDE) ", " MRT_OP("iy", P) ", " MRT_OP("nry", P) "\n"                      \
+	"v_fma_f32 v53, " MRT_NEAR_##BZ(RS, Z, SIDE) ", " MRT_OP("iz", P) ", " MRT_OP("nrz", P) "\n"                      \
+	"v_fma_f32 v54, " MRT_FAR_##BX(RS, X, SIDE) ", " MRT_OP("ix", P) ", " MRT_OP("nrx", P) "\n"                       \
+	"v_fma_f32 v55, " MRT_FAR_##BY(RS, Y, SIDE) ", " MRT_OP("iy", P) ", " MRT_OP("nry", P) "\n"                       \
+	"v_fma_f32 v57, " MRT_FAR_##BZ(RS, Z, SIDE) ", " MRT_OP("iz", P) ", " MRT_OP("nrz", P) "\n"                       \
+	"v_max_f32 v53, v53, " MRT_OP("tmin", P) "\n"                                                                   \
+	"v_min_f32 v57, v57, " MRT_OP("lim", P) "\n"                                                                    \
+	"v_max3_f32 " TE ", v51, v52, v53\n"                                                                            \
+	"v_min3_f32 v54, v54, v55, v57\n"                                                                               \
+	"v_cmp_le_f32_e64 " MASK ", " TE ", v54\n"
+
+// one child (SIDE = L / R, TE its entry register, CULLBITS the lanes of the cull mask that speak for it): both groups
+#define MRT_ROWSC_CHILD(SIDE, TE, CULLBITS, MA, MB, BX, BY, BZ)                                                       \
+	"s_and_b32 s48, s44, " CULLBITS "\n"          /* some plane has the whole box outside? */                       \
+	"s_cbranch_scc1 L_cull" #SIDE "_%=\n"                                                                           \
+	"s_cmp_eq_u64 s[60:61], 0\n"                                                                                    \
+	"s_cbranch_scc1 L_" #SIDE "A0_%=\n"                                                                             \
+	MRT_ROWS_SLAB1("A", RA, SIDE, TE, BX, BY, BZ, MA)                                                               \
+	"L_" #SIDE "A1_%=:\n"                                                                                           \
+	"s_cmp_eq_u64 s[62:63], 0\n"                                                                                    \
+	"s_cbranch_scc1 L_" #SIDE "B0_%=\n"                                                                             \
+	MRT_ROWS_SLAB1("B", RA, SIDE, TE, BX, BY, BZ, MB)                                                               \
+	"L_" #SIDE "B1_%=:\n"
+#define MRT_ROWSC_CHILD_OOL(SIDE, MA, MB)                                                                             \
+	"L_cull" #SIDE "_%=:\n"                                                                                         \
+	"s_mov_b64 " MA ", 0\n"                                                                                         \
+	"s_mov_b64 " MB ", 0\n"                                                                                         \
+	"s_branch L_" #SIDE "B1_%=\n"                                                                                   \
+	"L_" #SIDE "A0_%=:\n"                                                                                           \
+	"s_mov_b64 " MA ", 0\n"                                                                                         \
+	"s_branch L_" #SIDE "A1_%=\n"                                                                                   \
+	"L_" #SIDE "B0_%=:\n"                                                                                           \
+	"s_mov_b64 " MB ", 0\n"                                                                                         \
+	"s_branch L_" #SIDE "B1_%=\n"
+
+// In: cur (group A's operand) = a row to visit, the groups' own masks, the lane's cull constants.  Out: cur = 0x7FFFFFFF.
+// Stack entries as in MRT_ROWS_LOOPW.  v58..v60: the lane's three box coordinates (no far-child prefetch here).
+#define MRT_ROWS_LOOPC(CNT_N, CNT_T, CNT_P, ANYA, ANYB, ANYDONE, BX, BY, BZ)                                          \
+	asm volatile(                                                                                                   \
+		"s_mov_b64 s[60:61], %[maskA]\n"                                                                            \
+		"s_mov_b64 s[62:63], %[maskB]\n"                                                                            \
+		"L_loop_%=:\n"                                                                                              \
+		"s_lshl_b32 s52, %[curA], 6\n"                                                                              \
+		"s_load_dwordx16 s[20:35], %[rows], s52\n"                                                                  \
+		"s_bitcmp1_b32 %[curA], 31\n"                                                                               \
+		"s_cbranch_scc1 L_tri_%=\n"                                                                                 \
+		"v_add_u32 v58, s52, %[cox]\n"                                                                              \
+		"v_add_u32 v59, s52, %[coy]\n"                                                                              \
+		"v_add_u32 v60, s52, %[coz]\n"                                                                              \
+		"global_load_dword v58, v58, %[rows]\n"                                                                     \
+		"global_load_dword v59, v59, %[rows]\n"                                                                     \
+		"global_load_dword v60, v60, %[rows]\n"                                                                     \
+		CNT_N                                                                                                       \
+		"s_waitcnt vmcnt(0)\n"                                                                                      \
+		"v_mul_f32 v58, %[cnx], v58\n"                                                                              \
+		"v_fma_f32 v58, %[cny], v59, v58\n"                                                                         \
+		"v_fma_f32 v58, %[cnz], v60, v58\n"                                                                         \
+		"v_cmp_lt_f32_e64 s[44:45], v58, %[ccc]\n"    /* lanes 0..3: the left box is outside plane 0..3; 4..7: the right box */ \
+		"s_waitcnt lgkmcnt(0)\n"                                                                                    \
+		MRT_ROWSC_CHILD(L, "v50", "0x0f", "s[36:37]", "s[40:41]", BX, BY, BZ)                                       \
+		MRT_ROWSC_CHILD(R, "v56", "0xf0", "s[38:39]", "s[42:43]", BX, BY, BZ)                                       \
+		"s_or_b64 s[44:45], s[36:37], s[40:41]\n"    /* any lane of the 128 hit the left child?  */                 \
+		"s_cbranch_scc0 L_lmiss_%=\n"                                                                               \
+		"s_or_b64 vcc, s[38:39], s[42:43]\n"         /* ... the right child? */                                     \
+		"s_cbranch_scc0 L_onlyl_%=\n"                                                                               \
+		/* both: lane 0 of the group tested last (its tl, tr are still in v50, v56) decides which is nearer */      \
+		"v_cmp_lt_f32_e64 s[46:47], v50, v56\n"      /* (order = speed only) */                                     \
+		"s_bitcmp1_b32 s46, 0\n"                                                                                    \
+		"s_cselect_b32 s53, " RA_RREF ", " RA_LREF "\n"       /* far  */                                            \
+		"s_cselect_b32 %[curA], " RA_LREF ", " RA_RREF "\n"   /* near */                                            \
+		"s_cselect_b64 s[50:51], s[38:39], s[36:37]\n"        /* the far child's masks: group A, group B */         \
+		"s_cselect_b64 s[58:59], s[42:43], s[40:41]\n"                                                              \
+		"s_cselect_b64 s[60:61], s[36:37], s[38:39]\n"        /* the near child's */                                \
+		"s_cselect_b64 s[62:63], s[40:41], s[42:43]\n"                                                              \
+		"v_mov_b32 v50, s50\n"                                                                                      \
+		"v_mov_b32 v51, s51\n"                                                                                      \
+		"v_mov_b32 v52, s58\n"                                                                                      \
+		"v_mov_b32 v53, s59\n"                                                                                      \
+		"v_mov_b32 v54, s53\n"                                                                                      \
+		"ds_write_b128 %[spA], v[50:53]\n"                                                                          \
+		"ds_write_b32 %[spA], v54 offset:16\n"                                                                      \
+		"v_add_u32 %[spA], 32, %[spA]\n"                                                                            \
+		CNT_P                                                                                                       \
+		"s_branch L_loop_%=\n"                                                                                      \
+		"L_onlyl_%=:\n"                                                                                             \
+		"s_mov_b32 %[curA], " RA_LREF "\n"                                                                          \
+		"s_mov_b64 s[60:61], s[36:37]\n"                                                                            \
+		"s_mov_b64 s[62:63], s[40:41]\n"                                                                            \
+		"s_branch L_loop_%=\n"                                                                                      \
+		"L_lmiss_%=:\n"                                                                                             \
+		"s_or_b64 vcc, s[38:39], s[42:43]\n"                                                                        \
+		"s_cbranch_scc0 L_pop_%=\n"                                                                                 \
+		"s_mov_b32 %[curA], " RA_RREF "\n"                                                                          \
+		"s_mov_b64 s[60:61], s[38:39]\n"                                                                            \
+		"s_mov_b64 s[62:63], s[42:43]\n"                                                                            \
+		"s_branch L_loop_%=\n"                                                                                      \
+		"L_tri_%=:\n"                                                                                               \
+		CNT_T                                                                                                       \
+		"s_waitcnt lgkmcnt(0)\n"                                                                                    \
+		"s_cmp_eq_u64 s[60:61], 0\n"                                                                                \
+		"s_cbranch_scc1 L_Atnext_%=\n"                                                                              \
+		MRT_ROWS_TRI_TEST("A", RA, "s[60:61]", "%[curA]", ANYA)                                                     \
+		"s_cmp_eq_u64 s[62:63], 0\n"                                                                                \
+		"s_cbranch_scc1 L_Btnext_%=\n"                                                                              \
+		MRT_ROWS_TRI_TEST("B", RA, "s[62:63]", "%[curA]", ANYB)                                                     \
+		ANYDONE                                                                                                     \
+		"s_bitcmp1_b32 " RA_FLAGS ", 0\n"        /* the last triangle of its leaf? */                               \
+		"s_cbranch_scc1 L_pop_%=\n"                                                                                 \
+		"s_add_u32 %[curA], %[curA], 1\n"                                                                           \
+		"s_branch L_loop_%=\n"                                                                                      \
+		"L_pop_%=:\n"                                                                                               \
+		"v_add_u32 %[spA], -32, %[spA]\n"                                                                           \
+		"ds_read_b128 v[50:53], %[spA]\n"                                                                           \
+		"ds_read_b32 v54, %[spA] offset:16\n"                                                                       \
+		"s_waitcnt lgkmcnt(0)\n"                                                                                    \
+		"v_readfirstlane_b32 %[curA], v54\n"                                                                        \
+		"v_readfirstlane_b32 s60, v50\n"                                                                            \
+		"v_readfirstlane_b32 s61, v51\n"                                                                            \
+		"v_readfirstlane_b32 s62, v52\n"                                                                            \
+		"v_readfirstlane_b32 s63, v53\n"                                                                            \
+		"s_cmp_lg_u32 %[curA], 0x7fffffff\n"                                                                        \
+		"s_cbranch_scc1 L_loop_%=\n"                                                                                \
+		"s_branch L_exit_%=\n"                                                                                      \
+		MRT_ROWSC_CHILD_OOL(L, "s[36:37]", "s[40:41]")                                                              \
+		MRT_ROWSC_CHILD_OOL(R, "s[38:39]", "s[42:43]")                                                              \
+		"L_exit_%=:\n"                                                                                              \
+		"s_waitcnt vmcnt(0)\n"                                                                                      \
+		"s_mov_b64 %[maskA], s[60:61]\n"                                                                            \
+		"s_mov_b64 %[maskB], s[62:63]\n"                                                                            \
+		: MRT_ROWS_OUT(A, a), [limB] "+v"(b.lim), [btB] "+v"(b.bt), [buB] "+v"(b.bu), [bvB] "+v"(b.bv),             \
+		  [bsB] "+v"(b.bs), [biB] "+v"(b.bi), [maskB] "+s"(b.mask), [cntn] "+s"(cnt_n), [cntt] "+s"(cnt_t), [cntp] "+s"(sp_max) \
+		: MRT_ROWS_IN(A, a), MRT_ROWS_IN(B, b), [rows] "s"(rows), [qmask] "s"(qmask), [eps] "s"(eps), [vneg] "v"(vneg), \
+		  [cnx] "v"(cull.nx), [cny] "v"(cull.ny), [cnz] "v"(cull.nz), [ccc] "v"(cull.cc), [cox] "v"(cull.ox), [coy] "v"(cull.oy), [coz] "v"(cull.oz) \
+		: MRT_ROWS_CLOBBERS)
+
+// the lane's share of the packet's culling pyramid (lanes 0..7; see MRT_ROWS_LOOPC)
+struct CullRegs {
+	float nx, ny, nz, cc;    // inward normal of the lane's plane (pushed outwards), dot(n, apex) - eps; cc = -inf: never culls
+	uint32_t ox, oy, oz;     // byte offsets, within a node row, of the lane's box's corner farthest along n
+};
+
 // counting builds of the one-packet loop also clock the row fetch: shader cycles from before the s_load to after
 // its s_waitcnt (two s_memtime reads included), summed per wave in %[cntw]
 #define MRT_ROWS_T_PRE "s_memtime s[64:65]\n s_waitcnt lgkmcnt(0)\n"
@@ -506,6 +667,91 @@ __device__ __forceinline__ void rows_walk_wide(const float4 *rows, uint32_t qmas
 	sp_max = __builtin_amdgcn_readfirstlane(sp_max);
 }
 
+template <int OCT, bool ANY_HIT, bool COUNT>
+__device__ __forceinline__ void rows_walk_cull(const float4 *rows, uint32_t qmask, PacketRegs &a, PacketRegs &b, const CullRegs &cull, uint32_t &cnt_n, uint32_t &cnt_t, uint32_t &sp_max)
+{
+	const float eps = 1e-8f, vneg = -FLT_MAX;
+#define MRT_WC(O, BX, BY, BZ)                                                                                         \
+	if (OCT == O) {                                                                                                 \
+		if (COUNT) { if (ANY_HIT) MRT_ROWS_LOOPC(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWS_CNT_P, MRT_ROWSW_ANYHIT("A"), MRT_ROWSW_ANYHIT("B"), MRT_ROWSW_ANYDONE, BX, BY, BZ); \
+			else MRT_ROWS_LOOPC(MRT_ROWS_CNT_N, MRT_ROWS_CNT_T, MRT_ROWS_CNT_P, MRT_ROWS_NEAREST("A"), MRT_ROWS_NEAREST("B"), "", BX, BY, BZ); } \
+		else { if (ANY_HIT) MRT_ROWS_LOOPC("", "", "", MRT_ROWSW_ANYHIT("A"), MRT_ROWSW_ANYHIT("B"), MRT_ROWSW_ANYDONE, BX, BY, BZ); \
+			else MRT_ROWS_LOOPC("", "", "", MRT_ROWS_NEAREST("A"), MRT_ROWS_NEAREST("B"), "", BX, BY, BZ); }        \
+	}
+	MRT_WC(0, 0, 0, 0) MRT_WC(1, 1, 0, 0) MRT_WC(2, 0, 1, 0) MRT_WC(3, 1, 1, 0) MRT_WC(4, 0, 0, 1) MRT_WC(5, 1, 0, 1) MRT_WC(6, 0, 1, 1) MRT_WC(7, 1, 1, 1)
+#undef MRT_WC
+	rows_uniform(a);
+	cnt_n = __builtin_amdgcn_readfirstlane(cnt_n); cnt_t = __builtin_amdgcn_readfirstlane(cnt_t);
+	sp_max = __builtin_amdgcn_readfirstlane(sp_max);
+}
+
+// The packet's culling pyramid.  Culling is on only if every ray of the two tiles starts at one point (bit for bit),
+// has t_min >= 0, and lies inside the four planes through the corner rays (lane 0 / 56 of tile A, lane 7 / 63 of tile B
+// = the corners of the 16x8 block when B is A's right-hand neighbour) pushed outwards by 5e-5 rad: checked here for
+// every lane, so any other arrangement (tiles on different image rows, rays that are not a pinhole grid, a partial
+// tile without its corner lanes) simply does not cull.  Soundness: a box is skipped only if fl(dot(n', corner)) <
+// fl(dot(n', apex)) - eps with eps = 8 * 2^-24 * |n'|_1 * (largest scene coordinate + |apex|_1), more than both
+// roundings together, so the true dot(n', corner - apex) is negative, the corner being the box's farthest point along
+// n': no point of the box is on the inner side of that plane, and every ray point o + t d, t >= 0, is (dot(n', d) >=
+// 1e-5 |d| was checked with the same roundings to spare).  The slab test such a ray makes against such a box fails
+// by a margin (>= 1e-5 of the distance) three orders above its own rounding, so the skipped tests were all-false masks.
+__device__ __forceinline__ CullRegs cull_setup(const RayRegs &ra, const RayRegs &rb, bool valid_a, bool valid_b, unsigned long long part_a,
+		unsigned long long part_b, float scene_abs_max, uint32_t lane)
+{
+	CullRegs c;
+	c.nx = 0.0f; c.ny = 0.0f; c.nz = 0.0f; c.cc = -__builtin_inff(); c.ox = 0u; c.oy = 0u; c.oz = 0u;
+	const bool corners = (part_a & 1ull) && (part_a >> 56 & 1ull) && (part_b >> 7 & 1ull) && (part_b >> 63 & 1ull);
+	if (!corners) return c; // (wave-uniform)
+#define MRT_RL(v, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l))
+	const float ox = MRT_RL(ra.ox, 0), oy = MRT_RL(ra.oy, 0), oz = MRT_RL(ra.oz, 0);
+	const float tl[3] = { MRT_RL(ra.dx, 0), MRT_RL(ra.dy, 0), MRT_RL(ra.dz, 0) }, bl[3] = { MRT_RL(ra.dx, 56), MRT_RL(ra.dy, 56), MRT_RL(ra.dz, 56) };
+	const float tr[3] = { MRT_RL(rb.dx, 7), MRT_RL(rb.dy, 7), MRT_RL(rb.dz, 7) }, br[3] = { MRT_RL(rb.dx, 63), MRT_RL(rb.dy, 63), MRT_RL(rb.dz, 63) };
+#undef MRT_RL
+	float cen[3] = { tl[0] + tr[0] + bl[0] + br[0], tl[1] + tr[1] + bl[1] + br[1], tl[2] + tr[2] + bl[2] + br[2] };
+	const float cl = __builtin_sqrtf(cen[0] * cen[0] + cen[1] * cen[1] + cen[2] * cen[2]);
+	if (!(cl > 0.0f)) return c;
+	cen[0] /= cl; cen[1] /= cl; cen[2] /= cl;
+	// the lane's plane: k = lane & 3 -> (top, right, bottom, left) = cross of the two corner rays on that side
+	const uint32_t k = lane & 3u;
+	const float *pa = k == 0u ? tl : (k == 1u ? tr : (k == 2u ? br : bl)), *pb = k == 0u ? tr : (k == 1u ? br : (k == 2u ? bl : tl));
+	float n[3] = { pa[1] * pb[2] - pa[2] * pb[1], pa[2] * pb[0] - pa[0] * pb[2], pa[0] * pb[1] - pa[1] * pb[0] };
+	const float nl = __builtin_sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+	bool ok = nl > 0.0f;
+	const float inv = ok ? 1.0f / nl : 0.0f;
+	n[0] *= inv; n[1] *= inv; n[2] *= inv;
+	if (n[0] * cen[0] + n[1] * cen[1] + n[2] * cen[2] < 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
+	const float push = 5e-5f;
+	n[0] += push * cen[0]; n[1] += push * cen[1]; n[2] += push * cen[2];
+	// every lane checks its own two rays against ALL four planes: the planes of lanes 0..3 (readlane), not only its own
+	bool inside = true;
+	for (int q = 0; q < 4; q++) {
+		const float qx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n[0]), q)),
+				qy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n[1]), q)),
+				qz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n[2]), q));
+		const float da = qx * ra.dx + qy * ra.dy + qz * ra.dz, la = __builtin_sqrtf(ra.dx * ra.dx + ra.dy * ra.dy + ra.dz * ra.dz);
+		const float db = qx * rb.dx + qy * rb.dy + qz * rb.dz, lb = __builtin_sqrtf(rb.dx * rb.dx + rb.dy * rb.dy + rb.dz * rb.dz);
+		if (valid_a && !(da >= 1e-5f * la)) inside = false;
+		if (valid_b && !(db >= 1e-5f * lb)) inside = false;
+	}
+	if (valid_a && !(ra.ox == ox && ra.oy == oy && ra.oz == oz && ra.t_min >= 0.0f)) inside = false;
+	if (valid_b && !(rb.ox == ox && rb.oy == oy && rb.oz == oz && rb.t_min >= 0.0f)) inside = false;
+	ok = ok && __builtin_isfinite(n[0]) && __builtin_isfinite(n[1]) && __builtin_isfinite(n[2]);
+	const bool planes_ok = (__ballot(ok) & 0xFull) == 0xFull; // the four planes (lanes 0..3 hold one each)
+	if (__ballot(!inside) != 0ull || !planes_ok) return c;
+	if (lane >= 8u) return c; // the other lanes load the row's first dword and never cull
+	const float n1 = __builtin_fabsf(n[0]) + __builtin_fabsf(n[1]) + __builtin_fabsf(n[2]);
+	const float o1 = __builtin_fabsf(ox) + __builtin_fabsf(oy) + __builtin_fabsf(oz);
+	const float err = 8.0f * 5.9604645e-8f * n1 * (scene_abs_max + o1);
+	const float cc = (n[0] * ox + n[1] * oy + n[2] * oz) - err;
+	if (!__builtin_isfinite(cc)) return c;
+	const uint32_t box = (lane >> 2) & 1u; // 0: the left child (row dwords 0..6), 1: the right one (8..14); min at +0, max at +4
+	c.nx = n[0]; c.ny = n[1]; c.nz = n[2]; c.cc = cc;
+	c.ox = 4u * (box * 8u + (n[0] >= 0.0f ? 4u : 0u) + 0u);
+	c.oy = 4u * (box * 8u + (n[1] >= 0.0f ? 4u : 0u) + 1u);
+	c.oz = 4u * (box * 8u + (n[2] >= 0.0f ? 4u : 0u) + 2u);
+	return c;
+}
+
 __device__ __forceinline__ void rows_init(PacketRegs &s, const RayRegs &r, bool takes_part, uint32_t sp)
 {
 	s.ox = r.ox; s.oy = r.oy; s.oz = r.oz; s.dx = r.dx; s.dy = r.dy; s.dz = r.dz; s.tmin = r.t_min;
@@ -533,7 +779,8 @@ __device__ __forceinline__ int rows_octant(const RayRegs &r, bool part, unsigned
 // WG = threads per workgroup: 256 (four waves on neighbouring tiles share a CU and its scalar cache: C5 20.9 against
 // 22.6 ms) or 64 (a wave slot is refilled as soon as ITS wave ends, not when a workgroup's worth of slots is free:
 // C3 2.06 against 2.17 ms); api.hip picks by the size of the scene.
-template <bool ANY_HIT, bool COUNT, int PACKETS, int WG>
+// CULL: paired packets walk with packet-level frustum culling (MRT_ROWS_LOOPC).
+template <bool ANY_HIT, bool COUNT, int PACKETS, int WG, bool CULL = false>
 __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS_WPE, 8))) void trace_packet_rows_kernel(const TraceParams p)
 {
 	// per wave and packet: 16-byte stack entries {ref, -, lane mask}; entry 0 holds the sentinel
@@ -581,9 +828,16 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS_WPE
 		*(volatile uint32_t *)&stack_a[4] = kSentinel;
 		A.sp += 16u; // (= stack base + 32)
 		A.mask = part_a; B.mask = part_b;
+		if (CULL) {
+			const CullRegs cull = cull_setup(ra, rb, valid_a, valid_b, part_a, part_b, p.scene_abs_max, lane);
+#define MRT_RWC(O) case O: rows_walk_cull<O, ANY_HIT, COUNT>(rows, p.query_mask, A, B, cull, cnt_n, cnt_t, sp_wide); break;
+			switch (oct_a) { MRT_RWC(0) MRT_RWC(1) MRT_RWC(2) MRT_RWC(3) MRT_RWC(4) MRT_RWC(5) MRT_RWC(6) MRT_RWC(7) }
+#undef MRT_RWC
+		} else {
 #define MRT_RW2(O) case O: rows_walk_wide<O, ANY_HIT, COUNT>(rows, p.query_mask, A, B, cnt_n, cnt_t, sp_wide); break;
 		switch (oct_a) { MRT_RW2(0) MRT_RW2(1) MRT_RW2(2) MRT_RW2(3) MRT_RW2(4) MRT_RW2(5) MRT_RW2(6) MRT_RW2(7) }
 #undef MRT_RW2
+		}
 		done_a = done_b = true;
 	}
 	// packets that could not be paired (different octants: tiles on an image axis; a single packet): one at a time

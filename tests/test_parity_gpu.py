@@ -185,6 +185,30 @@ def test_ragged_batch_sizes(ctx, soup1k, count):
     parity.assert_exact(ctx.cast(rays), want, f"n={count} sorted")
 
 
+def test_packet_frustum_culling_skips_no_hit(built):
+    """mrt_options.packet_cull = 2: the 128-ray walk skips a child box that lies wholly outside the pyramid of the packet's
+    rays.  Whatever it skips, the records must be the oracle's: pinhole grids (culling active: one apex per packet), clipped
+    grids and partial waves (tiles without their corner lanes: culling off for that packet), rays with different origins
+    flagged coherent, a camera inside the scene (boxes around the apex: the error bound must keep them), any-hit."""
+    v = synth.soup(40000, 0.3, 21)
+    scene, osc = capi.Scene(v), po.OracleScene(v)
+    c = capi.Context(0, kernel=capi.KERNEL_PACKET_DUAL, packet_cull=2)
+    scene.upload(c)
+    for origin, fwd, (w, h), fov in (((0, 0, -12), (0, 0, 1), (256, 128), 50.0), ((0.3, -0.2, 0.1), (0.2, 0.9, -0.3), (128, 96), 75.0),
+                                     ((0, 0, -12), (0, 0, 1), (130, 35), 50.0), ((9, 8, -7), (-1, -0.9, 0.8), (64, 64), 20.0)):
+        cam = capi.camera_look(origin, fwd, w, h, fov)
+        g = po.grid_rays(origin, fwd, w, h, fov)
+        want = osc.trace(g)
+        parity.assert_exact(c.cast_grid(cam, w, h), want, f"culling walk, grid {w}x{h} from {origin}")
+        parity.assert_exact(c.cast(g, flags=capi.FLAG_COHERENT), want, f"culling walk, cast of {w}x{h} from {origin}")
+        any_got = c.cast_grid(cam, w, h, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT).astype(bool)
+        assert np.array_equal(any_got, want["prim_id"] >= 0)
+    assert c.stats()["last_kernel"] == capi.KERNEL_PACKET_DUAL
+    inc = synth.incoherent_rays(20000, 5)                         # no common apex: every packet must decline to cull
+    parity.assert_exact(c.cast(inc, flags=capi.FLAG_COHERENT), osc.trace(inc), "culling walk, incoherent rays flagged coherent")
+    c.close()
+
+
 @pytest.mark.parametrize("kernel", [capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_ROWS, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_QUAD])
 def test_partial_waves_and_clipped_tiles_on_every_packet_kernel(built, kernel):
     """Packets whose wave is not full: COHERENT batches of 1 .. 1000 rays (the last wave partial; at count = 1 lanes

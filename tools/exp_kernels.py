@@ -51,6 +51,8 @@ VARIANTS = {
     "dual_cast": (dict(kernel=capi.KERNEL_PACKET_DUAL), "cast"),
     "dual_fused_zorder": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=2), "fused"),
     "dual_fused_rowmajor": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=1), "fused"),
+    "dual_cull_fused": (dict(kernel=capi.KERNEL_PACKET_DUAL, packet_cull=2), "fused"),
+    "dual_cull_cast": (dict(kernel=capi.KERNEL_PACKET_DUAL, packet_cull=2), "cast"),
     "quad_fused": (dict(kernel=capi.KERNEL_PACKET_QUAD), "fused"),
     "quad_cast": (dict(kernel=capi.KERNEL_PACKET_QUAD), "cast"),
     "auto_cast": (dict(), "cast"),
