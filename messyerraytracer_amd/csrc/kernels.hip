@@ -694,7 +694,10 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 	if ((p.kernel == MRT_KERNEL_PACKET_DUAL || p.kernel == MRT_KERNEL_PACKET_ROWS) && p.row_array != nullptr) {
 		// the walk over the unified row array: one or two packets per wave (two: half the waves)
 		const uint32_t packets = p.kernel == MRT_KERNEL_PACKET_DUAL ? 2u : 1u;
-		const uint32_t rows_wg = packets == 2u && p.rows_wg == 64u ? 64u : (uint32_t)MRT_WG;
+#ifndef MRT_ROWS_WG_LARGE
+#define MRT_ROWS_WG_LARGE MRT_WG // threads per workgroup of the rows kernel on large scenes
+#endif
+		const uint32_t rows_wg = packets == 2u && p.rows_wg == 64u ? 64u : (packets == 2u ? (uint32_t)MRT_ROWS_WG_LARGE : (uint32_t)MRT_WG);
 		const uint64_t rblocks = (threads + packets * rows_wg - 1) / (packets * rows_wg);
 		dim3 rgrid((uint32_t)rblocks), rwg(rows_wg);
 #define MRT_LAUNCH_ROWS(A, C, N, W, F) hipLaunchKernelGGL((trace_packet_rows_kernel<A, C, N, W, F>), rgrid, rwg, p.extra_lds, stream, p)
@@ -705,7 +708,7 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		} while (0)
 		const bool cull = packets == 2u && p.rows_cull != 0u;
 		if (packets == 2u && rows_wg == 64u) { if (cull) MRT_LAUNCH_ROWS_AC(2, 64, true); else MRT_LAUNCH_ROWS_AC(2, 64, false); }
-		else if (packets == 2u) { if (cull) MRT_LAUNCH_ROWS_AC(2, MRT_WG, true); else MRT_LAUNCH_ROWS_AC(2, MRT_WG, false); }
+		else if (packets == 2u) { if (cull) MRT_LAUNCH_ROWS_AC(2, MRT_ROWS_WG_LARGE, true); else MRT_LAUNCH_ROWS_AC(2, MRT_ROWS_WG_LARGE, false); }
 		else MRT_LAUNCH_ROWS_AC(1, MRT_WG, false);
 #undef MRT_LAUNCH_ROWS_AC
 #undef MRT_LAUNCH_ROWS
