@@ -201,7 +201,7 @@ uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent, uint64_t count)
 int build_rows(mrt_ctx *ctx)
 {
 	// the 4-wide rows: when the 4-wide layout is resident and its worst-case stack fits the wave's 64 entries
-	const bool wanted4 = ctx->opts.kernel == MRT_KERNEL_AUTO || ctx->opts.kernel == MRT_KERNEL_PACKET_QUAD;
+	const bool wanted4 = ctx->opts.kernel == MRT_KERNEL_PACKET_QUAD; // (AUTO never picks the four-wide walk: it is no faster)
 	const uint64_t n_units4 = (uint64_t)2u * ctx->n_nodes4 + ctx->n_tris;
 	if (wanted4 && ctx->d_nodes4 && ctx->n_nodes4 && ctx->stack4 <= 64u && n_units4 < mrt::kAsmNodeLimit) {
 		if (hipMalloc(&ctx->d_rows4, (size_t)n_units4 * 64u) != hipSuccess) { ctx->d_rows4 = nullptr; (void)hipGetLastError(); }
