@@ -206,8 +206,9 @@ enum {
 	                                  (compressed wide BVH, cf. the reference's cwbvh_traverse.comp.glsl), one
 	                                  128-byte line per step (default for large incoherent batches)       */
 	MRT_KERNEL_PACKET_DUAL = 9, /* the packet walk end to end in gfx950 assembly over ONE array of 64-byte rows (nodes +
-	                               triangles), TWO packets per wave in lockstep: twice the fetches in flight at the same
-	                               occupancy (the packet walk is latency-bound); default for coherent batches        */
+	                               triangles), 128 rays per wave: two neighbouring 8x8 tiles share one walk (one fetch,
+	                               one stack, one near / far decision per step; the box and triangle tests once per
+	                               tile that owns the row); default for coherent batches of >= 2^22 rays            */
 	MRT_KERNEL_PACKET_ROWS = 10, /* the same walk with one packet per wave                                           */
 	MRT_KERNEL_PACKET_QUAD = 11, /* the 128-ray shared walk over FOUR-wide node rows (128 bytes: the 4-wide collapse of the
 	                                same tree, exact boxes): half the row fetches for the same box tests
