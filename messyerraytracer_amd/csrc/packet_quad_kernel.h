@@ -2,7 +2,7 @@
 // instruction stream cut to what gfx950 issues cheaply.  Included by kernels.hip (inside namespace mrt, after
 // packet_rows_kernel.h, whose triangle test and operand macros it reuses).
 //
-// What the second half of round 2 measured (tools/ubench_issue.hip, ubench_pk.hip, ubench_fetch.hip; counters of
+// What the second half of round 2 measured (tools/ubench/issue_cost.hip, ubench/pk_fma_issue.hip, ubench/row_fetch.hip; counters of
 // trace_packet_rows_kernel<2> in profiles/r02d_*), at 8 waves per SIMD:
 //   * a wave's row-fetch waits are HIDDEN by the other waves: halving the fetches per packet (four-wide rows, the
 //     first version of this file) cut the waits from 68 to 44 thousand cycles per wave and the kernel time by nothing;

@@ -1,4 +1,4 @@
-// ubench_exec.hip — does a wave64 vector instruction cost less when half (or most) of EXEC is off?  gfx950, 8 waves per SIMD.
+// ubench/exec_mask.hip — does a wave64 vector instruction cost less when half (or most) of EXEC is off?  gfx950, 8 waves per SIMD.
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>

@@ -1,5 +1,5 @@
-// ubench_issue.hip — what a wave pays per instruction kind inside a VALU-heavy loop on gfx950, at 1 and 8 waves per SIMD.
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_issue.hip -o tools/_bin/ubench_issue && tools/_bin/ubench_issue
+// ubench/issue_cost.hip — what a wave pays per instruction kind inside a VALU-heavy loop on gfx950, at 1 and 8 waves per SIMD.
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/issue_cost.hip -o tools/_bin/ubench_issue && tools/_bin/ubench_issue
 // Loop body = 40 independent v_fma_f32 (the slab arithmetic of one node step) + 10 copies of a probe:
 //   none      nothing
 //   salu      s_add_u32

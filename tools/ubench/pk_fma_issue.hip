@@ -1,4 +1,4 @@
-// ubench_pk.hip — issue cost of v_pk_fma_f32 against v_fma_f32 on gfx950 (8 waves per SIMD, every CU).
+// ubench/pk_fma_issue.hip — issue cost of v_pk_fma_f32 against v_fma_f32 on gfx950 (8 waves per SIMD, every CU).
 #include <hip/hip_runtime.h>
 #include <cstdint>
 #include <cstdio>

@@ -1,5 +1,5 @@
-// ubench_fetch.hip — what a wave pays for a dependent chain of row fetches on gfx950, by fetch path.
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_fetch.hip -o gpurun_out/ubench_fetch && gpurun_out/ubench_fetch
+// ubench/row_fetch.hip — what a wave pays for a dependent chain of row fetches on gfx950, by fetch path.
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench/row_fetch.hip -o tools/_bin/ubench_fetch && tools/_bin/ubench_fetch   (through gpurun)
 // Every wave chases pointers through a table of 64-byte rows (row r holds the index of the next row in dword 0 and
 // of a second, unrelated row in dword 1); the table is far larger than any cache below the L2 or small enough to sit
 // in it.  Variants:
