@@ -71,6 +71,22 @@ def test_create_without_gpu_fails_loudly(built):
     assert e.value.status == capi.ERR_NO_DEVICE
 
 
+def test_options_are_validated_before_a_device_is_asked_for(built):
+    """Unknown kernel ids (the retired 3 and 4 included) and out-of-range tuning knobs are MRT_ERR_INVALID, with or
+    without a GPU; a valid selection of a packet walk gets as far as the device check."""
+    for kw in (dict(kernel=3), dict(kernel=4), dict(kernel=12), dict(packet_wg=100), dict(packet_cull=3)):
+        with pytest.raises(capi.MrtError) as e:
+            capi.Context(0, **kw)
+        assert e.value.status == capi.ERR_INVALID, kw
+    assert capi.kernel_name(capi.KERNEL_PACKET_QUAD) == "trace_packet_quad_kernel"
+    import torch
+    if not torch.cuda.is_available():
+        for kw in (dict(kernel=capi.KERNEL_PACKET_QUAD), dict(packet_wg=64, packet_cull=2)):
+            with pytest.raises(capi.MrtError) as e:
+                capi.Context(0, **kw)
+            assert e.value.status == capi.ERR_NO_DEVICE, kw
+
+
 @pytest.mark.parametrize("n,s,seed", [(1, 0.5, 1), (2, 0.5, 2), (3, 0.5, 3), (7, 0.5, 4), (1000, 0.5, 1), (60000, 0.15, 7)])
 def test_builder_equals_oracle_builder(built, n, s, seed):
     """mrt_bvh2_build == the restatement of tinybvh::BVH::Build, for any thread count."""

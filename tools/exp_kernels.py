@@ -51,6 +51,8 @@ VARIANTS = {
     "dual_cast": (dict(kernel=capi.KERNEL_PACKET_DUAL), "cast"),
     "dual_fused_zorder": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=2), "fused"),
     "dual_fused_rowmajor": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=1), "fused"),
+    "dual_fused_swz": (dict(kernel=capi.KERNEL_PACKET_DUAL, xcd_swizzle=1), "fused"),
+    "dual_fused_zorder32": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=3), "fused"),
     "dual_cull_fused": (dict(kernel=capi.KERNEL_PACKET_DUAL, packet_cull=2), "fused"),
     "dual_cull_cast": (dict(kernel=capi.KERNEL_PACKET_DUAL, packet_cull=2), "cast"),
     "quad_fused": (dict(kernel=capi.KERNEL_PACKET_QUAD), "fused"),
