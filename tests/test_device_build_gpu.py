@@ -99,6 +99,12 @@ def test_device_resident_triangles_and_rebuild(built):
     _check(c, po.OracleScene(v), "clustering after the radix tree")
     c.build_scene_device(capi.make_triangles(v))
     _check(c, po.OracleScene(v), "radix tree after clustering")
+    # the builder's arena grows when a larger scene arrives (and is kept for the smaller ones after it)
+    big = synth.soup(30000, 0.25, 12)
+    c.build_scene_device(capi.make_triangles(big), ploc=True)
+    _check(c, po.OracleScene(big), "larger scene after smaller ones (clustering)")
+    c.build_scene_device(capi.make_triangles(v))
+    _check(c, po.OracleScene(v), "smaller scene in the grown arena")
     with pytest.raises(capi.MrtError):
         c.build_scene_device(np.zeros(0, dtype=T.TRI64))
     c.close()
