@@ -73,6 +73,9 @@ struct mrt_ctx {
 	// what detect_grid_kernel decided, also written to this host-mapped word block {row width, rows, tiles_x, verdict}
 	// so that the host knows after the stream sync which of the two queued kernels did the work (no extra copy)
 	uint32_t *h_auto = nullptr, *d_auto_host = nullptr;
+	// small host-array casts (RayDispatcher::cast_ray / any_hit: one ray; tiles of a few hundred rays): rays and hits go
+	// through two pinned, device-mapped buffers instead of two DMA copies (mrt_cast)
+	void *h_small_in = nullptr, *d_small_in = nullptr, *h_small_out = nullptr, *d_small_out = nullptr;
 	uint32_t queued_kernel = 0, queued_alt_kernel = 0; bool queued_detect = false; // what the last enqueue_cast put on the stream
 	// host-array pipeline (cast_host_pipelined): copy streams and per-chunk events, created on first use
 	hipStream_t up_stream = nullptr, dn_stream = nullptr;
@@ -181,13 +184,18 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent, uint64_t count)
 {
 	// a two-level scene has its own pair of kernels (two_level_kernel.h)
-	if (ctx->two_level) return coherent && ctx->opts.kernel != MRT_KERNEL_LANE ? mrt::MRT_KERNEL_TWO_LEVEL_PACKET : mrt::MRT_KERNEL_TWO_LEVEL;
+	// Packets pay once there are enough of them: a wave that walks for 64 rays is a long serial chain (0.3 - 0.7 ms on a
+	// 1 M-triangle scene, the longer the wider its 8x8 tile opens), and a small batch is over when its slowest wave is.
+	// Coherent grids on the C3 scene (tools/bench_small_batches.py, profiles/r02d_small_batches.txt): 64^2 rays 0.69 ms by
+	// packets, 0.32 ms one lane per ray; 128^2 0.56 / 0.40; 256^2 0.40 / 0.43; 512^2 0.35 / 0.59 (C2 scene: even at 128^2).
+	const bool few = ctx->opts.kernel == MRT_KERNEL_AUTO && count < (1ull << 15);
+	if (ctx->two_level) return coherent && !few && ctx->opts.kernel != MRT_KERNEL_LANE ? mrt::MRT_KERNEL_TWO_LEVEL_PACKET : mrt::MRT_KERNEL_TWO_LEVEL;
 	if (ctx->opts.kernel == MRT_KERNEL_PACKET_DUAL || ctx->opts.kernel == MRT_KERNEL_PACKET_ROWS)
 		return !coherent ? MRT_KERNEL_LANE : (ctx->d_rows ? ctx->opts.kernel : MRT_KERNEL_PACKET_ASM);
 	if (ctx->opts.kernel == MRT_KERNEL_PACKET_QUAD)
 		return !coherent ? MRT_KERNEL_LANE : (ctx->d_rows4 ? MRT_KERNEL_PACKET_QUAD : MRT_KERNEL_PACKET_ASM);
 	if (ctx->opts.kernel >= MRT_KERNEL_LANE && ctx->opts.kernel <= MRT_KERNEL_LANE8_PERSISTENT) return ctx->opts.kernel;
-	if (!coherent) return MRT_KERNEL_LANE;
+	if (!coherent || few) return MRT_KERNEL_LANE;
 	// Coherent batches: the 128-ray shared walk over the row array (packet_rows_kernel.h) once the batch is large
 	// enough to fill the chip with half as many waves (C3 2.16 -> 2.06 ms, C5 23.2 -> 21.2 ms; C2's 2^20 rays are
 	// 7 % faster with one packet per wave: 0.188 against 0.202 ms), else the 64-ray packet kernel with the
@@ -346,7 +354,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	const bool any = mode == MRT_MODE_ANY_HIT;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	ctx->queued_detect = detect; ctx->queued_alt_kernel = 0;
-	if (detect && ctx->opts.kernel == MRT_KERNEL_AUTO && !ctx->opts.count_visits) {
+	if (detect && ctx->opts.kernel == MRT_KERNEL_AUTO && !ctx->opts.count_visits && p.kernel != MRT_KERNEL_LANE && p.kernel != mrt::MRT_KERNEL_TWO_LEVEL) {
 		// The caller said "coherent"; the device checks.  Packet launch first, lane launch behind it:
 		// detect_grid_kernel's verdict (d_auto[3]) makes exactly one of them do the work.
 		p.skip_flag = p.auto_grid + 3; p.skip_when = 1u;
@@ -375,6 +383,8 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	*d_hits_out = d_hits;
 	return MRT_OK;
 }
+
+constexpr uint64_t kSmallCast = 1024; // rays: host-array casts up to this size take the mapped-memory path of mrt_cast
 
 int finish_timing(mrt_ctx *ctx, bool h2d, bool sorted, bool d2h)
 {
@@ -562,6 +572,8 @@ void mrt_destroy(mrt_ctx *ctx)
 	if (ctx->d_counters) (void)hipFree(ctx->d_counters);
 	if (ctx->build_arena.ptr) (void)hipFree(ctx->build_arena.ptr);
 	if (ctx->h_auto) (void)hipHostFree(ctx->h_auto);
+	if (ctx->h_small_in) (void)hipHostFree(ctx->h_small_in);
+	if (ctx->h_small_out) (void)hipHostFree(ctx->h_small_out);
 	for (auto &e : ctx->ev) if (e) (void)hipEventDestroy(e);
 	for (auto &e : ctx->pipe_ev) (void)hipEventDestroy(e);
 	if (ctx->up_stream) (void)hipStreamDestroy(ctx->up_stream);
@@ -934,6 +946,31 @@ int mrt_cast(mrt_ctx *ctx, const void *rays, void *hits, uint64_t count, uint32_
 	if (!hits_dev && !(flags & MRT_FLAG_RAYS_ON_DEVICE) && count >= 2 * kPipeChunk && !ctx->opts.count_visits) {
 		if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded (is_available() == false)");
 		return cast_host_pipelined(ctx, rays, hits, count, query_mask, mode, flags);
+	}
+	// Latency path: host arrays of at most kSmallCast rays skip both DMA copies: the kernel reads the rays from, and
+	// writes the records to, pinned host memory mapped into the device (one ray: 85 -> 55 us per blocking call,
+	// tools/bench_latency.py).  The same kernels, the same records.
+	if (!hits_dev && !(flags & (MRT_FLAG_RAYS_ON_DEVICE | MRT_FLAG_ASYNC)) && count <= kSmallCast && !ctx->opts.count_visits) {
+		const size_t rs_ = ray_stride(flags), hs_ = hit_stride(flags, mode);
+		if (!ctx->h_small_in) {
+			if (hipHostMalloc(&ctx->h_small_in, kSmallCast * 64, hipHostMallocMapped) != hipSuccess ||
+					hipHostMalloc(&ctx->h_small_out, kSmallCast * 64, hipHostMallocMapped) != hipSuccess ||
+					hipHostGetDevicePointer(&ctx->d_small_in, ctx->h_small_in, 0) != hipSuccess ||
+					hipHostGetDevicePointer(&ctx->d_small_out, ctx->h_small_out, 0) != hipSuccess) {
+				if (ctx->h_small_in) (void)hipHostFree(ctx->h_small_in);
+				if (ctx->h_small_out) (void)hipHostFree(ctx->h_small_out);
+				ctx->h_small_in = ctx->h_small_out = ctx->d_small_in = ctx->d_small_out = nullptr;
+				(void)hipGetLastError();
+			}
+		}
+		if (ctx->h_small_in) {
+			std::memcpy(ctx->h_small_in, rays, count * rs_);
+			int rc2 = enqueue_cast(ctx, ctx->d_small_in, ctx->d_small_out, count, query_mask, mode, flags | MRT_FLAG_RAYS_ON_DEVICE, &d_hits);
+			if (rc2) return rc2;
+			HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+			std::memcpy(hits, ctx->h_small_out, count * hs_);
+			return finish_timing(ctx, false, ctx->stats.last_kernel_launches >= 2, false);
+		}
 	}
 	int rc = enqueue_cast(ctx, rays, hits_dev ? hits : nullptr, count, query_mask, mode, flags, &d_hits);
 	if (rc) return rc;

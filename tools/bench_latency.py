@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Latency of small host-array casts through the C-ABI (mrt_cast with host pointers, blocking): what
+RayDispatcher::cast_ray / any_hit (one ray) and small cast_rays batches pay on the GPU backend.
+    python tools/bench_latency.py"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from messyerraytracer_amd import capi, synth, types as T  # noqa: E402
+
+
+def main():
+    v = synth.soup(100000, 0.1, 1)
+    scene = capi.Scene(v)
+    c = capi.Context(0)
+    scene.upload(c)
+    inc = synth.incoherent_rays(4096, 3)
+    d_grid = c.device_alloc(64 * 64 * 32)
+    c.generate_grid(capi.camera_look((0, 0, -12), (0, 0, 1), 64, 64, 50.0), 64, 64, 0, 64, d_grid)
+    grid = np.zeros(4096, dtype=T.RAY32)
+    c.d2h(grid, d_grid)
+    out = {}
+    for n in (1, 16, 256, 1024, 4096):
+        hits = np.zeros(n, dtype=T.HIT32)
+        for rays, flags, name in ((inc, 0, "incoherent"), (inc, capi.FLAG_COHERENT, "incoherent_flagged_coherent"), (grid, capi.FLAG_COHERENT, "grid_rows_coherent"),
+                                  (grid, 0, "grid_rows_unflagged")):
+            for _ in range(20):
+                c.cast(rays[:n], hits, flags=flags)
+            ts = []
+            for _ in range(200):
+                t0 = time.perf_counter()
+                c.cast(rays[:n], hits, flags=flags)
+                ts.append(time.perf_counter() - t0)
+            out[f"{name}_{n}"] = dict(median_us=float(np.median(ts)) * 1e6, p10_us=float(np.percentile(ts, 10)) * 1e6)
+            print(f"{name:28s} n={n:5d}  median {np.median(ts) * 1e6:8.1f} us   p10 {np.percentile(ts, 10) * 1e6:8.1f} us", flush=True)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
