@@ -17,7 +17,7 @@ from messyerraytracer_amd import capi, synth, types as T  # noqa: E402
 def main():
     v = synth.soup(100000, 0.1, 1)
     scene = capi.Scene(v)
-    c = capi.Context(0)
+    c = capi.Context(0, kernel=int(sys.argv[1]) if len(sys.argv) > 1 else 0)
     scene.upload(c)
     inc = synth.incoherent_rays(4096, 3)
     d_grid = c.device_alloc(64 * 64 * 32)
