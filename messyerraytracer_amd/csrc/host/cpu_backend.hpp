@@ -28,77 +28,94 @@
 
 namespace mrt {
 
-// ThreadPool::dispatch_and_wait, thread_pool.h:77-133: chunks = workers + 1, chunk = ceil(count / chunks), the caller
-// runs chunk 0, the workers grab the rest from an atomic counter, a condition variable ends the wait.
+// The pool behind RayDispatcher's CPU path.  Contract taken from src/dispatch/thread_pool.h:41-55,77-133 (its text is not
+// followed): helpers = hardware_concurrency - 1 persistent threads; dispatch_and_wait(count, min_batch, body) runs
+// body(0, count) inline for small batches, otherwise cuts [0, count) into helpers + 1 equal spans, runs span 0 on the
+// calling thread while the helpers claim the others, and returns when every span has run.
+//
+// How this one works: a dispatch is a "ticket" = (epoch << 32 | next unclaimed span) in ONE atomic word.  A helper that
+// wakes for epoch e claims spans by compare-and-swap on that word and stops the moment the word carries another epoch,
+// so a helper that is late for e can never touch the spans of e + 1 with e's parameters; completion is a countdown of
+// spans (not of helpers), so a dispatch does not wait for helpers that found nothing left to do.
 class ThreadPool {
 public:
-	explicit ThreadPool(uint32_t threads = 0) // thread_pool.h:35-57: hardware_concurrency - 1 workers
+	explicit ThreadPool(uint32_t helpers = 0)
 	{
-		uint32_t hw = std::thread::hardware_concurrency();
-		thread_count_ = threads ? threads : (hw > 1 ? hw - 1 : 0);
-		for (uint32_t i = 0; i < thread_count_; i++) workers_.emplace_back([this] { worker_loop(); });
+		const uint32_t cores = std::thread::hardware_concurrency();
+		n_helpers_ = helpers ? helpers : (cores > 1 ? cores - 1 : 0);
+		helpers_.reserve(n_helpers_);
+		for (uint32_t i = 0; i < n_helpers_; i++) helpers_.emplace_back(&ThreadPool::helper_main, this);
 	}
 	~ThreadPool()
 	{
-		{ std::lock_guard<std::mutex> lock(mutex_); shutdown_ = true; }
-		cv_work_.notify_all();
-		for (auto &t : workers_) if (t.joinable()) t.join();
+		{ std::lock_guard<std::mutex> g(gate_); quitting_ = true; }
+		wake_.notify_all();
+		for (std::thread &t : helpers_) t.join();
 	}
 	ThreadPool(const ThreadPool &) = delete;
 	ThreadPool &operator=(const ThreadPool &) = delete;
 
-	void dispatch_and_wait(int count, int min_batch_size, const std::function<void(int, int)> &func)
+	void dispatch_and_wait(int count, int min_batch_size, const std::function<void(int, int)> &body)
 	{
 		if (count <= 0) return;
-		if (count <= min_batch_size || thread_count_ == 0) { func(0, count); return; }
-		const uint32_t num_chunks = thread_count_ + 1;
-		const int chunk_size = (int)(((uint32_t)count + num_chunks - 1) / num_chunks);
+		if (n_helpers_ == 0 || count <= min_batch_size) { body(0, count); return; }
+		const int spans = (int)n_helpers_ + 1, len = (count + spans - 1) / spans;
+		const int used = (count + len - 1) / len;           // spans that hold at least one item
+		uint32_t epoch;
 		{
-			std::lock_guard<std::mutex> lock(mutex_);
-			work_func_ = &func; work_chunk_size_ = chunk_size; work_total_ = count;
-			work_next_chunk_.store(1);          // chunk 0 is the calling thread's
-			pending_workers_ = thread_count_;   // every worker reports once per generation
-			work_generation_++;
+			std::lock_guard<std::mutex> g(gate_);
+			epoch = ++epoch_;
+			body_ = &body; total_ = count; span_len_ = len; span_count_ = used;
+			unfinished_.store(used, std::memory_order_relaxed);
+			ticket_.store((uint64_t)epoch << 32 | 1u, std::memory_order_release); // span 0 belongs to the caller
 		}
-		cv_work_.notify_all();
-		func(0, std::min(chunk_size, count));
-		std::unique_lock<std::mutex> lock(mutex_);
-		cv_done_.wait(lock, [this] { return pending_workers_ == 0; });
+		wake_.notify_all();
+		run_span(body, 0, len, count);
+		std::unique_lock<std::mutex> g(gate_);
+		all_done_.wait(g, [this] { return unfinished_.load(std::memory_order_acquire) == 0; });
 	}
-	uint32_t thread_count() const { return thread_count_; }
+	uint32_t thread_count() const { return n_helpers_; }
 
 private:
-	std::vector<std::thread> workers_;
-	uint32_t thread_count_ = 0;
-	std::mutex mutex_;
-	std::condition_variable cv_work_, cv_done_;
-	bool shutdown_ = false;
-	const std::function<void(int, int)> *work_func_ = nullptr;
-	int work_chunk_size_ = 0, work_total_ = 0;
-	std::atomic<uint32_t> work_next_chunk_{0};
-	uint32_t pending_workers_ = 0;
-	uint64_t work_generation_ = 0;
+	std::vector<std::thread> helpers_;
+	uint32_t n_helpers_ = 0;
+	std::mutex gate_;
+	std::condition_variable wake_, all_done_;
+	bool quitting_ = false;
+	uint32_t epoch_ = 0;                          // guarded by gate_
+	const std::function<void(int, int)> *body_ = nullptr;
+	int total_ = 0, span_len_ = 0, span_count_ = 0;
+	std::atomic<uint64_t> ticket_{0};
+	std::atomic<int> unfinished_{0};
 
-	void worker_loop()
+	void run_span(const std::function<void(int, int)> &body, int span, int len, int total)
 	{
-		uint64_t last_gen = 0;
+		const long long lo = (long long)span * len;
+		body((int)lo, (int)std::min<long long>(lo + len, total));
+		if (unfinished_.fetch_sub(1, std::memory_order_acq_rel) == 1) {
+			std::lock_guard<std::mutex> g(gate_); // the waiter is either before its predicate check or inside wait()
+			all_done_.notify_all();
+		}
+	}
+	void helper_main()
+	{
+		uint32_t seen = 0;
 		for (;;) {
-			const std::function<void(int, int)> *func; int chunk_size, total;
+			const std::function<void(int, int)> *body; int total, len, n_spans; uint32_t epoch;
 			{
-				std::unique_lock<std::mutex> lock(mutex_);
-				cv_work_.wait(lock, [this, last_gen] { return shutdown_ || work_generation_ > last_gen; });
-				if (shutdown_) return;
-				last_gen = work_generation_;
-				func = work_func_; chunk_size = work_chunk_size_; total = work_total_;
+				std::unique_lock<std::mutex> g(gate_);
+				wake_.wait(g, [&] { return quitting_ || epoch_ != seen; });
+				if (quitting_) return;
+				seen = epoch = epoch_;
+				body = body_; total = total_; len = span_len_; n_spans = span_count_;
 			}
-			for (;;) {
-				const uint32_t chunk = work_next_chunk_.fetch_add(1);
-				const long long start = (long long)chunk * chunk_size;
-				if (start >= total) break;
-				(*func)((int)start, (int)std::min<long long>(start + chunk_size, total));
+			uint64_t t = ticket_.load(std::memory_order_acquire);
+			while ((uint32_t)(t >> 32) == epoch && (int)(uint32_t)t < n_spans) {
+				if (ticket_.compare_exchange_weak(t, t + 1, std::memory_order_acq_rel, std::memory_order_acquire)) {
+					run_span(*body, (int)(uint32_t)t, len, total);
+					t = ticket_.load(std::memory_order_acquire);
+				}
 			}
-			std::lock_guard<std::mutex> lock(mutex_);
-			if (--pending_workers_ == 0) cv_done_.notify_one();
 		}
 	}
 };

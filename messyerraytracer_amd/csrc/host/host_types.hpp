@@ -50,16 +50,21 @@ struct Ray {
 	Vector3 at(float t) const { return origin + direction * t; }
 
 private:
+	// contract of src/core/ray.h:78-89: 1 / d per axis, a component with |d| < 1e-9 gets +-1e9 by the sign test d < 0
+	// (so -0.0f gets +1e9, and a NaN stays a NaN); dir_sign = (d < 0)
+	static float reciprocal_clamped(float c)
+	{
+		constexpr float tiny = 1e-9f;
+		if (!(std::fabs(c) < tiny)) return 1.0f / c;
+		const float huge = 1.0f / tiny;
+		return c < 0.0f ? -huge : huge;
+	}
 	void _precompute()
 	{
-		const float eps = 1e-9f;
-		auto safe_inv = [eps](float d) -> float {
-			return (std::fabs(d) < eps) ? ((d < 0.0f) ? (-1.0f / eps) : (1.0f / eps)) : (1.0f / d);
-		};
-		inv_direction = Vector3(safe_inv(direction.x), safe_inv(direction.y), safe_inv(direction.z));
-		dir_sign[0] = (direction.x < 0.0f) ? 1 : 0;
-		dir_sign[1] = (direction.y < 0.0f) ? 1 : 0;
-		dir_sign[2] = (direction.z < 0.0f) ? 1 : 0;
+		const float c[3] = { direction.x, direction.y, direction.z };
+		float r[3];
+		for (int a = 0; a < 3; a++) { r[a] = reciprocal_clamped(c[a]); dir_sign[a] = c[a] < 0.0f ? 1 : 0; }
+		inv_direction = Vector3(r[0], r[1], r[2]);
 	}
 };
 static_assert(sizeof(Ray) == 60, "Ray must be 60 bytes");
@@ -75,7 +80,12 @@ struct Intersection {
 	uint32_t hit_layers;
 	static constexpr uint32_t NO_HIT = UINT32_MAX;
 	Intersection() : t(FLT_MAX), position(), normal(), u(0.0f), v(0.0f), prim_id(NO_HIT), hit_layers(0) {}
-	void set_miss() { t = FLT_MAX; u = 0.0f; v = 0.0f; prim_id = NO_HIT; hit_layers = 0; }
+	void set_miss() // everything but position / normal back to the default record (intersection.h:45-52 leaves those two alone)
+	{
+		const Vector3 keep_p = position, keep_n = normal;
+		*this = Intersection();
+		position = keep_p; normal = keep_n;
+	}
 	bool hit() const { return prim_id != NO_HIT; }
 };
 static_assert(sizeof(Intersection) == 44, "Intersection must be 44 bytes");
@@ -88,12 +98,7 @@ struct Triangle {
 	uint32_t layers;
 	Triangle() : id(0), layers(0xFFFFFFFF) {}
 	Triangle(const Vector3 &a, const Vector3 &b, const Vector3 &c, uint32_t p_id, uint32_t p_layers = 0xFFFFFFFF)
-		: v0(a), v1(b), v2(c), id(p_id), layers(p_layers)
-	{
-		edge1 = v1 - v0;
-		edge2 = v2 - v0;
-		normal = edge1.cross(edge2).normalized();
-	}
+		: v0(a), v1(b), v2(c), edge1(b - a), edge2(c - a), normal(edge1.cross(edge2).normalized()), id(p_id), layers(p_layers) {}
 };
 static_assert(sizeof(Triangle) == 80, "Triangle must be 80 bytes");
 

@@ -178,17 +178,14 @@ private:
 		if (count == 0) return MRT_OK;
 		if (!scene_.built) { std::fprintf(stderr, "[RayDispatcher] CPU backend: no scene built\n"); return MRT_ERR_NO_SCENE; }
 		const CpuWalker w = _walker();
-		if (!stats) {
-			pool_.dispatch_and_wait(count, MIN_BATCH_FOR_THREADING, [&](int start, int end) { for (int i = start; i < end; i++) per_ray(w, i, nullptr); });
-			return MRT_OK;
-		}
-		std::vector<RayStats> chunk_stats(pool_.thread_count() + 1);
-		std::atomic<uint32_t> slot_counter{0};
-		pool_.dispatch_and_wait(count, MIN_BATCH_FOR_THREADING, [&](int start, int end) {
-			RayStats &local = chunk_stats[slot_counter.fetch_add(1, std::memory_order_relaxed)];
-			for (int i = start; i < end; i++) per_ray(w, i, &local);
+		// one tally per span of the pool's split (at most helpers + 1), handed out in arrival order, summed at the end
+		std::vector<RayStats> tallies(stats ? pool_.thread_count() + 1 : 0);
+		std::atomic<uint32_t> tally_cursor{0};
+		pool_.dispatch_and_wait(count, MIN_BATCH_FOR_THREADING, [&](int first, int last) {
+			RayStats *mine = stats ? &tallies[tally_cursor.fetch_add(1, std::memory_order_relaxed)] : nullptr;
+			for (int i = first; i < last; i++) per_ray(w, i, mine);
 		});
-		for (const auto &cs : chunk_stats) *stats += cs;
+		for (const RayStats &t : tallies) *stats += t;
 		return MRT_OK;
 	}
 

@@ -364,6 +364,27 @@ struct PacketRegs {
 	"s_branch L_exit_%=\n"                                                                                          \
 	"L_goon_%=:\n"
 
+// Both child rows are pulled into the scalar cache as soon as the node's own row has arrived, before the slab tests:
+// the row fetch of the next step (whichever child it visits) then finds its line there instead of waiting for the L2
+// (two one-dword scalar loads into the triangle test's temporaries s64 / s65, which nothing reads; they are long back
+// when the next step waits on lgkmcnt).  The far-child vector prefetch of round 1 is the alternative (MRT_ROWS_KPREFETCH=0).
+#ifndef MRT_ROWS_KPREFETCH
+#define MRT_ROWS_KPREFETCH 1
+#endif
+#if MRT_ROWS_KPREFETCH
+#define MRT_ROWSW_KPREFETCH                                                                                           \
+	"s_lshl_b32 s48, " RA_LREF ", 6\n"                                                                               \
+	"s_lshl_b32 s49, " RA_RREF ", 6\n"                                                                               \
+	"s_load_dword s64, %[rows], s48\n"                                                                              \
+	"s_load_dword s65, %[rows], s49\n"
+#define MRT_ROWSW_FARPREFETCH ""
+#else
+#define MRT_ROWSW_KPREFETCH ""
+#define MRT_ROWSW_FARPREFETCH                                                                                         \
+	"v_lshlrev_b32 v55, 6, v54\n"           /* pull the pushed row towards the L2 now */                            \
+	"global_load_dword v60, v55, %[rows]\n" /* v60 is never read (vmcnt drained at the very end) */
+#endif
+
 // In: cur (group A's operand) = a row to visit, the groups' own masks.  Out: cur = 0x7FFFFFFF.
 // Stack entries are 32 bytes: {group A's mask, group B's mask, ref, -}; the sentinel entry has ref 0x7FFFFFFF.
 #define MRT_ROWS_LOOPW(CNT_N, CNT_T, CNT_P, ANYA, ANYB, ANYDONE, BX, BY, BZ)                                                 \
@@ -377,6 +398,7 @@ struct PacketRegs {
 		"s_bitcmp1_b32 %[curA], 31\n"                                                                               \
 		"s_cbranch_scc1 L_tri_%=\n"                                                                                 \
 		CNT_N                                                                                                       \
+		MRT_ROWSW_KPREFETCH                                                                                         \
 		MRT_ROWSW_GROUP_SLAB("A", "s[60:61]", "s[36:37]", "s[38:39]", BX, BY, BZ)                                   \
 		MRT_ROWSW_GROUP_SLAB("B", "s[62:63]", "s[40:41]", "s[42:43]", BX, BY, BZ)                                   \
 		"s_or_b64 s[44:45], s[36:37], s[40:41]\n"    /* any lane of the 128 hit the left child?  */                 \
@@ -401,8 +423,7 @@ struct PacketRegs {
 		"ds_write_b32 %[spA], v54 offset:16\n"                                                                      \
 		"v_add_u32 %[spA], 32, %[spA]\n"                                                                            \
 		CNT_P                                                                                                       \
-		"v_lshlrev_b32 v55, 6, v54\n"           /* pull the pushed row towards the L2 now */                        \
-		"global_load_dword v60, v55, %[rows]\n" /* v60 is never read (vmcnt drained at the very end) */             \
+		MRT_ROWSW_FARPREFETCH                                                                                       \
 		"s_branch L_loop_%=\n"                                                                                      \
 		"L_onlyl_%=:\n"                                                                                             \
 		"s_mov_b32 %[curA], " RA_LREF "\n"                                                                          \
@@ -454,21 +475,30 @@ struct PacketRegs {
 		: MRT_ROWS_CLOBBERS)
 
 
-// ---- the 128-ray walk with packet-level frustum culling (round 2, after the walk was found vector-issue bound) -----
-// 46 % of the (group, child box) slab tests of a C3 packet fail for all 64 rays of the group (47 % at C5), and 92-97 %
-// of those boxes lie wholly outside the pyramid the packet's rays span: the packet can skip a child's 22 per-ray
-// instructions after a test that costs 10, done by eight lanes at once.
-// MEASURED (profiles/r02d_frustum_cull.txt): vector instructions per wave 10 388 -> 9 109 at C3, results identical,
-// and the kernel 8 % SLOWER (C3 1.99 -> 2.15 ms, C5 21.1 -> 23.2 ms): the lanes get their box corners by vector loads,
-// whose latency (SQ_WAIT_ANY 106 -> 183 thousand cycles per wave) eight waves no longer hide.  Every other way to put
-// three of the row's twelve coordinates into eight different lanes costs more vector instructions than the skipped
-// tests save.  Kept behind mrt_options.packet_cull = 2 (off by default), held to the oracle by the packet tests.
-// Lane l < 8 stands for (child b = l >> 2, side plane k = l & 3) of the packet's pyramid (apex = the common ray origin,
-// planes through the corner rays, pushed outwards): it loads the three coordinates of the box's corner that lies
-// farthest along the plane's inward normal n' (a per-lane byte offset into the row each), forms dot(n', corner) and
-// compares it with cc = dot(n', apex) - eps.  Smaller: the whole box is outside that plane, no ray of the packet
-// reaches it, both groups' tests of that child are skipped (masks zero).  See cull_setup() for n', eps and the
-// conditions under which a packet culls at all (else cc = -inf and nothing is ever skipped).
+// ---- the 128-ray walk with packet-level frustum culling ---------------------------------------------------------
+// The ownership model (tools/sim_ownership.py, profiles/r03_ownership_sim_c3.json): of the (group, child box) slab
+// tests a C3 packet executes, 46 % fail for all 64 rays of the group, and 87 % of those boxes lie wholly outside the
+// pyramid the packet's 128 rays span: 40 % of the vector work of the walk buys nothing.  A box outside one side plane of
+// the pyramid is one no ray of the packet reaches; both groups' tests of that child are skipped (masks zero).
+// Round 2's form of the test (three per-lane loads per step, waited for on the spot) cost more than it saved: the
+// kernel ran 8 % slower.  This form:
+//   * ONE vector load per row brings the row's 16 dwords to lanes 0..15 of every 16-lane row of the wave (lane l reads
+//     dword l & 15: the same 64-byte line for all four rows), so the four rows of the wave see the node's two child
+//     boxes side by side: row r of the wave stands for side plane r of the pyramid;
+//   * a lane multiplies its coordinate by its weight — the plane normal's component of that axis if the coordinate is
+//     the one of the box's corner farthest along the normal, else 0 — and three DPP row_shr adds leave
+//     dot(n', far corner) of the left child in lane 7 and of the right child in lane 15 of each row; one v_cmp against
+//     the lane's constant cc = dot(n', apex) - eps (-inf in the other lanes) gives the cull bits: 6 vector
+//     instructions per node step against 11 per (group, box) test skipped;
+//   * the loads are issued ONE STEP AHEAD: when a node's row has arrived (scalar path) the vector copies of BOTH child
+//     rows are requested, and waited for at the top of the next step, after this step's slab tests; a popped row's
+//     copy is requested at the pop, beside its scalar fetch.  (The same loads pull both child rows towards the L2 for
+//     the scalar fetch that follows: the far-child prefetch of MRT_ROWS_LOOPW is subsumed.)
+// Soundness: see cull_setup().  v60 / v61: the vector copies of the left / right child row (or, after a pop, v60 of the
+// popped row); s[66:67]: all ones when the current row's copy is the one in v61.  The weighted sum adds the products
+// of eight lanes, five of them with weight 0: the row's ref / count dwords (integers < 2^26 or leaf-flagged: denormal
+// bit patterns) times 0 are 0; a NaN or infinite coordinate (the padding box of a root leaf) makes the sum NaN and
+// the compare false: not culled.
 // One child box against one group (the arithmetic of MRT_ROWS_SLAB, one box at a time): TE = entry distance
 // (v50 for the left child, v56 for the right one: what the near / far decision reads), MASK = lanes that hit
 #define MRT_ROWS_SLAB1(P, RS, SIDE, TE, BX, BY, BZ, MASK)                                                             \
@@ -484,7 +514,7 @@ struct PacketRegs {
 	"v_min3_f32 v54, v54, v55, v57\n"                                                                               \
 	"v_cmp_le_f32_e64 " MASK ", " TE ", v54\n"
 
-// one child (SIDE = L / R, TE its entry register, CULLBITS the lanes of the cull mask that speak for it): both groups
+// one child (SIDE = L / R, TE its entry register, CULLBITS the bits of the cull word that speak for it): both groups
 #define MRT_ROWSC_CHILD(SIDE, TE, CULLBITS, MA, MB, BX, BY, BZ)                                                       \
 	"s_and_b32 s48, s44, " CULLBITS "\n"          /* some plane has the whole box outside? */                       \
 	"s_cbranch_scc1 L_cull" #SIDE "_%=\n"                                                                           \
@@ -498,6 +528,7 @@ struct PacketRegs {
 	"L_" #SIDE "B1_%=:\n"
 #define MRT_ROWSC_CHILD_OOL(SIDE, MA, MB)                                                                             \
 	"L_cull" #SIDE "_%=:\n"                                                                                         \
+	MRT_ROWSC_CNT_CULL                                                                                              \
 	"s_mov_b64 " MA ", 0\n"                                                                                         \
 	"s_mov_b64 " MB ", 0\n"                                                                                         \
 	"s_branch L_" #SIDE "B1_%=\n"                                                                                   \
@@ -507,33 +538,43 @@ struct PacketRegs {
 	"L_" #SIDE "B0_%=:\n"                                                                                           \
 	"s_mov_b64 " MB ", 0\n"                                                                                         \
 	"s_branch L_" #SIDE "B1_%=\n"
+#define MRT_ROWSC_CNT_CULL ""
+
+// request the vector copy of row REF (an SGPR) into VDST: lane l gets dword l & 15 of the row.  One vector instruction for
+// the address (the scalar unit is the busier one in this loop: three scalar instructions per request made it the bound).
+#define MRT_ROWSC_VLOAD(VDST, REF)                                                                                   \
+	"v_lshl_add_u32 v62, " REF ", 6, %[cvo]\n"                                                                      \
+	"global_load_dword " VDST ", v62, %[rows]\n"
 
 // In: cur (group A's operand) = a row to visit, the groups' own masks, the lane's cull constants.  Out: cur = 0x7FFFFFFF.
-// Stack entries as in MRT_ROWS_LOOPW.  v58..v60: the lane's three box coordinates (no far-child prefetch here).
+// Stack entries as in MRT_ROWS_LOOPW.
 #define MRT_ROWS_LOOPC(CNT_N, CNT_T, CNT_P, ANYA, ANYB, ANYDONE, BX, BY, BZ)                                          \
 	asm volatile(                                                                                                   \
 		"s_mov_b64 s[60:61], %[maskA]\n"                                                                            \
 		"s_mov_b64 s[62:63], %[maskB]\n"                                                                            \
+		"L_vload_%=:\n"                           /* the current row's vector copy is not on its way yet */          \
+		MRT_ROWSC_VLOAD("v60", "%[curA]")                                                                           \
+		"s_mov_b64 s[66:67], 0\n"                                                                                   \
 		"L_loop_%=:\n"                                                                                              \
 		"s_lshl_b32 s52, %[curA], 6\n"                                                                              \
 		"s_load_dwordx16 s[20:35], %[rows], s52\n"                                                                  \
+		"s_waitcnt lgkmcnt(0)\n"                                                                                    \
 		"s_bitcmp1_b32 %[curA], 31\n"                                                                               \
 		"s_cbranch_scc1 L_tri_%=\n"                                                                                 \
-		"v_add_u32 v58, s52, %[cox]\n"                                                                              \
-		"v_add_u32 v59, s52, %[coy]\n"                                                                              \
-		"v_add_u32 v60, s52, %[coz]\n"                                                                              \
-		"global_load_dword v58, v58, %[rows]\n"                                                                     \
-		"global_load_dword v59, v59, %[rows]\n"                                                                     \
-		"global_load_dword v60, v60, %[rows]\n"                                                                     \
 		CNT_N                                                                                                       \
-		"s_waitcnt vmcnt(0)\n"                                                                                      \
-		"v_mul_f32 v58, %[cnx], v58\n"                                                                              \
-		"v_fma_f32 v58, %[cny], v59, v58\n"                                                                         \
-		"v_fma_f32 v58, %[cnz], v60, v58\n"                                                                         \
-		"v_cmp_lt_f32_e64 s[44:45], v58, %[ccc]\n"    /* lanes 0..3: the left box is outside plane 0..3; 4..7: the right box */ \
-		"s_waitcnt lgkmcnt(0)\n"                                                                                    \
-		MRT_ROWSC_CHILD(L, "v50", "0x0f", "s[36:37]", "s[40:41]", BX, BY, BZ)                                       \
-		MRT_ROWSC_CHILD(R, "v56", "0xf0", "s[38:39]", "s[42:43]", BX, BY, BZ)                                       \
+		"s_waitcnt vmcnt(0)\n"                    /* the row's vector copy (requested a step ago, or at the pop) */  \
+		"v_cndmask_b32_e64 v58, v60, v61, s[66:67]\n"                                                               \
+		"v_mul_f32 v58, v58, %[cw]\n"                                                                               \
+		MRT_ROWSC_VLOAD("v60", RA_LREF)           /* both children's copies for the next step (also 2+ wait states */ \
+		"v_add_f32_dpp v59, v58, v58 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n" /* before each DPP read) */ \
+		MRT_ROWSC_VLOAD("v61", RA_RREF)                                                                             \
+		"v_add_f32_dpp v58, v59, v59 row_shr:2 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                           \
+		"s_nop 1\n"                                                                                                 \
+		"v_add_f32_dpp v59, v58, v58 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                           \
+		"v_cmp_lt_f32_e64 s[44:45], v59, %[ccc]\n" /* bit 16 r + 7: the left box is outside plane r; 16 r + 15: the right one */ \
+		"s_or_b32 s44, s44, s45\n"                                                                                  \
+		MRT_ROWSC_CHILD(L, "v50", "0x00800080", "s[36:37]", "s[40:41]", BX, BY, BZ)                                 \
+		MRT_ROWSC_CHILD(R, "v56", "0x80008000", "s[38:39]", "s[42:43]", BX, BY, BZ)                                 \
 		"s_or_b64 s[44:45], s[36:37], s[40:41]\n"    /* any lane of the 128 hit the left child?  */                 \
 		"s_cbranch_scc0 L_lmiss_%=\n"                                                                               \
 		"s_or_b64 vcc, s[38:39], s[42:43]\n"         /* ... the right child? */                                     \
@@ -547,6 +588,7 @@ struct PacketRegs {
 		"s_cselect_b64 s[58:59], s[42:43], s[40:41]\n"                                                              \
 		"s_cselect_b64 s[60:61], s[36:37], s[38:39]\n"        /* the near child's */                                \
 		"s_cselect_b64 s[62:63], s[40:41], s[42:43]\n"                                                              \
+		"s_cselect_b64 s[66:67], 0, -1\n"                     /* the near child's vector copy: v60 (left) / v61 */  \
 		"v_mov_b32 v50, s50\n"                                                                                      \
 		"v_mov_b32 v51, s51\n"                                                                                      \
 		"v_mov_b32 v52, s58\n"                                                                                      \
@@ -561,6 +603,7 @@ struct PacketRegs {
 		"s_mov_b32 %[curA], " RA_LREF "\n"                                                                          \
 		"s_mov_b64 s[60:61], s[36:37]\n"                                                                            \
 		"s_mov_b64 s[62:63], s[40:41]\n"                                                                            \
+		"s_mov_b64 s[66:67], 0\n"                                                                                   \
 		"s_branch L_loop_%=\n"                                                                                      \
 		"L_lmiss_%=:\n"                                                                                             \
 		"s_or_b64 vcc, s[38:39], s[42:43]\n"                                                                        \
@@ -568,10 +611,10 @@ struct PacketRegs {
 		"s_mov_b32 %[curA], " RA_RREF "\n"                                                                          \
 		"s_mov_b64 s[60:61], s[38:39]\n"                                                                            \
 		"s_mov_b64 s[62:63], s[42:43]\n"                                                                            \
+		"s_mov_b64 s[66:67], -1\n"                                                                                  \
 		"s_branch L_loop_%=\n"                                                                                      \
 		"L_tri_%=:\n"                                                                                               \
 		CNT_T                                                                                                       \
-		"s_waitcnt lgkmcnt(0)\n"                                                                                    \
 		"s_cmp_eq_u64 s[60:61], 0\n"                                                                                \
 		"s_cbranch_scc1 L_Atnext_%=\n"                                                                              \
 		MRT_ROWS_TRI_TEST("A", RA, "s[60:61]", "%[curA]", ANYA)                                                     \
@@ -594,24 +637,25 @@ struct PacketRegs {
 		"v_readfirstlane_b32 s62, v52\n"                                                                            \
 		"v_readfirstlane_b32 s63, v53\n"                                                                            \
 		"s_cmp_lg_u32 %[curA], 0x7fffffff\n"                                                                        \
-		"s_cbranch_scc1 L_loop_%=\n"                                                                                \
+		"s_cbranch_scc1 L_vload_%=\n"                                                                               \
 		"s_branch L_exit_%=\n"                                                                                      \
 		MRT_ROWSC_CHILD_OOL(L, "s[36:37]", "s[40:41]")                                                              \
 		MRT_ROWSC_CHILD_OOL(R, "s[38:39]", "s[42:43]")                                                              \
 		"L_exit_%=:\n"                                                                                              \
-		"s_waitcnt vmcnt(0)\n"                                                                                      \
+		"s_waitcnt vmcnt(0)\n"               /* no copy may land in v60 / v61 once the compiler owns them again */  \
 		"s_mov_b64 %[maskA], s[60:61]\n"                                                                            \
 		"s_mov_b64 %[maskB], s[62:63]\n"                                                                            \
 		: MRT_ROWS_OUT(A, a), [limB] "+v"(b.lim), [btB] "+v"(b.bt), [buB] "+v"(b.bu), [bvB] "+v"(b.bv),             \
 		  [bsB] "+v"(b.bs), [biB] "+v"(b.bi), [maskB] "+s"(b.mask), [cntn] "+s"(cnt_n), [cntt] "+s"(cnt_t), [cntp] "+s"(sp_max) \
-		: MRT_ROWS_IN(A, a), MRT_ROWS_IN(B, b), [rows] "s"(rows), [qmask] "s"(qmask), [eps] "s"(eps), [vneg] "v"(vneg), \
-		  [cnx] "v"(cull.nx), [cny] "v"(cull.ny), [cnz] "v"(cull.nz), [ccc] "v"(cull.cc), [cox] "v"(cull.ox), [coy] "v"(cull.oy), [coz] "v"(cull.oz) \
-		: MRT_ROWS_CLOBBERS)
+		: MRT_ROWS_IN(A, a), MRT_ROWS_IN(B, b), [rows] "s"(rows), [qmask] "s"(qmask),                                \
+		  [eps] "s"(eps), [vneg] "v"(vneg), [cw] "v"(cull.w), [ccc] "v"(cull.cc), [cvo] "v"(cull.voff)               \
+		: MRT_ROWS_CLOBBERS, "v61", "v62")
 
-// the lane's share of the packet's culling pyramid (lanes 0..7; see MRT_ROWS_LOOPC)
+// the lane's share of the packet's culling pyramid (see MRT_ROWS_LOOPC)
 struct CullRegs {
-	float nx, ny, nz, cc;    // inward normal of the lane's plane (pushed outwards), dot(n, apex) - eps; cc = -inf: never culls
-	uint32_t ox, oy, oz;     // byte offsets, within a node row, of the lane's box's corner farthest along n
+	float w;          // weight of the lane's row dword: a component of the lane's plane normal, or 0
+	float cc;         // lanes 7 and 15 of each 16-lane row: dot(n', apex) - eps; -inf elsewhere (and everywhere: never culls)
+	uint32_t voff;    // byte offset of the lane's dword in a row
 };
 
 // counting builds of the one-packet loop also clock the row fetch: shader cycles from before the s_load to after
@@ -689,30 +733,34 @@ __device__ __forceinline__ void rows_walk_cull(const float4 *rows, uint32_t qmas
 // has t_min >= 0, and lies inside the four planes through the corner rays (lane 0 / 56 of tile A, lane 7 / 63 of tile B
 // = the corners of the 16x8 block when B is A's right-hand neighbour) pushed outwards by 5e-5 rad: checked here for
 // every lane, so any other arrangement (tiles on different image rows, rays that are not a pinhole grid, a partial
-// tile without its corner lanes) simply does not cull.  Soundness: a box is skipped only if fl(dot(n', corner)) <
-// fl(dot(n', apex)) - eps with eps = 8 * 2^-24 * |n'|_1 * (largest scene coordinate + |apex|_1), more than both
-// roundings together, so the true dot(n', corner - apex) is negative, the corner being the box's farthest point along
-// n': no point of the box is on the inner side of that plane, and every ray point o + t d, t >= 0, is (dot(n', d) >=
-// 1e-5 |d| was checked with the same roundings to spare).  The slab test such a ray makes against such a box fails
-// by a margin (>= 1e-5 of the distance) three orders above its own rounding, so the skipped tests were all-false masks.
+// tile without its corner lanes) simply does not cull.  Soundness: a box is skipped only if S < fl(dot(n', apex)) - eps,
+// S = the rounded sum of the three rounded products n'_axis * corner_axis (relative error 2^-24 each, two real additions
+// of at most 2^-24 of the partial sum each: |S - dot(n', corner)| <= 3 * 2^-24 |n'|_1 max|coordinate|), the right-hand
+// side off by at most 4 * 2^-24 |n'|_1 |apex|_1, and eps = 8 * 2^-24 * |n'|_1 * (largest scene coordinate + |apex|_1),
+// more than both together: so the true dot(n', corner - apex) is negative, the corner being the box's farthest point
+// along n': no point of the box is on the inner side of that plane, and every ray point o + t d, t >= 0, is
+// (dot(n', d) >= 1e-5 |d| was checked with the same roundings to spare).  The slab test such a ray makes against such a
+// box fails by a margin (>= 1e-5 of the distance) three orders above its own rounding, so the skipped tests were
+// all-false masks.
+// Lane l: plane r = l >> 4 (top, right, bottom, left), row dword c = l & 15 = {lmin xyz, ref, lmax xyz, ref, rmin xyz, -,
+// rmax xyz, -}.
 __device__ __forceinline__ CullRegs cull_setup(const RayRegs &ra, const RayRegs &rb, bool valid_a, bool valid_b, unsigned long long part_a,
 		unsigned long long part_b, float scene_abs_max, uint32_t lane)
 {
 	CullRegs c;
-	c.nx = 0.0f; c.ny = 0.0f; c.nz = 0.0f; c.cc = -__builtin_inff(); c.ox = 0u; c.oy = 0u; c.oz = 0u;
+	c.w = 0.0f; c.cc = -__builtin_inff(); c.voff = (lane & 15u) * 4u;
 	const bool corners = (part_a & 1ull) && (part_a >> 56 & 1ull) && (part_b >> 7 & 1ull) && (part_b >> 63 & 1ull);
 	if (!corners) return c; // (wave-uniform)
 #define MRT_RL(v, l) __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l))
 	const float ox = MRT_RL(ra.ox, 0), oy = MRT_RL(ra.oy, 0), oz = MRT_RL(ra.oz, 0);
 	const float tl[3] = { MRT_RL(ra.dx, 0), MRT_RL(ra.dy, 0), MRT_RL(ra.dz, 0) }, bl[3] = { MRT_RL(ra.dx, 56), MRT_RL(ra.dy, 56), MRT_RL(ra.dz, 56) };
 	const float tr[3] = { MRT_RL(rb.dx, 7), MRT_RL(rb.dy, 7), MRT_RL(rb.dz, 7) }, br[3] = { MRT_RL(rb.dx, 63), MRT_RL(rb.dy, 63), MRT_RL(rb.dz, 63) };
-#undef MRT_RL
 	float cen[3] = { tl[0] + tr[0] + bl[0] + br[0], tl[1] + tr[1] + bl[1] + br[1], tl[2] + tr[2] + bl[2] + br[2] };
 	const float cl = __builtin_sqrtf(cen[0] * cen[0] + cen[1] * cen[1] + cen[2] * cen[2]);
 	if (!(cl > 0.0f)) return c;
 	cen[0] /= cl; cen[1] /= cl; cen[2] /= cl;
-	// the lane's plane: k = lane & 3 -> (top, right, bottom, left) = cross of the two corner rays on that side
-	const uint32_t k = lane & 3u;
+	// the lane's plane: k = lane >> 4 -> (top, right, bottom, left) = cross of the two corner rays on that side
+	const uint32_t k = lane >> 4;
 	const float *pa = k == 0u ? tl : (k == 1u ? tr : (k == 2u ? br : bl)), *pb = k == 0u ? tr : (k == 1u ? br : (k == 2u ? bl : tl));
 	float n[3] = { pa[1] * pb[2] - pa[2] * pb[1], pa[2] * pb[0] - pa[0] * pb[2], pa[0] * pb[1] - pa[1] * pb[0] };
 	const float nl = __builtin_sqrtf(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
@@ -722,33 +770,31 @@ __device__ __forceinline__ CullRegs cull_setup(const RayRegs &ra, const RayRegs 
 	if (n[0] * cen[0] + n[1] * cen[1] + n[2] * cen[2] < 0.0f) { n[0] = -n[0]; n[1] = -n[1]; n[2] = -n[2]; }
 	const float push = 5e-5f;
 	n[0] += push * cen[0]; n[1] += push * cen[1]; n[2] += push * cen[2];
-	// every lane checks its own two rays against ALL four planes: the planes of lanes 0..3 (readlane), not only its own
+	// every lane checks its own two rays against ALL four planes (lanes 0, 16, 32, 48 hold one each)
 	bool inside = true;
 	for (int q = 0; q < 4; q++) {
-		const float qx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n[0]), q)),
-				qy = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n[1]), q)),
-				qz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, n[2]), q));
+		const float qx = MRT_RL(n[0], 16 * q), qy = MRT_RL(n[1], 16 * q), qz = MRT_RL(n[2], 16 * q);
 		const float da = qx * ra.dx + qy * ra.dy + qz * ra.dz, la = __builtin_sqrtf(ra.dx * ra.dx + ra.dy * ra.dy + ra.dz * ra.dz);
 		const float db = qx * rb.dx + qy * rb.dy + qz * rb.dz, lb = __builtin_sqrtf(rb.dx * rb.dx + rb.dy * rb.dy + rb.dz * rb.dz);
 		if (valid_a && !(da >= 1e-5f * la)) inside = false;
 		if (valid_b && !(db >= 1e-5f * lb)) inside = false;
 	}
+#undef MRT_RL
 	if (valid_a && !(ra.ox == ox && ra.oy == oy && ra.oz == oz && ra.t_min >= 0.0f)) inside = false;
 	if (valid_b && !(rb.ox == ox && rb.oy == oy && rb.oz == oz && rb.t_min >= 0.0f)) inside = false;
 	ok = ok && __builtin_isfinite(n[0]) && __builtin_isfinite(n[1]) && __builtin_isfinite(n[2]);
-	const bool planes_ok = (__ballot(ok) & 0xFull) == 0xFull; // the four planes (lanes 0..3 hold one each)
+	const bool planes_ok = (__ballot(ok) & 0x0001000100010001ull) == 0x0001000100010001ull;
 	if (__ballot(!inside) != 0ull || !planes_ok) return c;
-	if (lane >= 8u) return c; // the other lanes load the row's first dword and never cull
 	const float n1 = __builtin_fabsf(n[0]) + __builtin_fabsf(n[1]) + __builtin_fabsf(n[2]);
 	const float o1 = __builtin_fabsf(ox) + __builtin_fabsf(oy) + __builtin_fabsf(oz);
 	const float err = 8.0f * 5.9604645e-8f * n1 * (scene_abs_max + o1);
 	const float cc = (n[0] * ox + n[1] * oy + n[2] * oz) - err;
-	if (!__builtin_isfinite(cc)) return c;
-	const uint32_t box = (lane >> 2) & 1u; // 0: the left child (row dwords 0..6), 1: the right one (8..14); min at +0, max at +4
-	c.nx = n[0]; c.ny = n[1]; c.nz = n[2]; c.cc = cc;
-	c.ox = 4u * (box * 8u + (n[0] >= 0.0f ? 4u : 0u) + 0u);
-	c.oy = 4u * (box * 8u + (n[1] >= 0.0f ? 4u : 0u) + 1u);
-	c.oz = 4u * (box * 8u + (n[2] >= 0.0f ? 4u : 0u) + 2u);
+	if (__ballot(!__builtin_isfinite(cc)) != 0ull) return c;
+	const uint32_t d = lane & 15u, axis = d & 3u;
+	const bool is_max = (d >> 2 & 1u) != 0u;
+	const float na = axis == 0u ? n[0] : (axis == 1u ? n[1] : n[2]);
+	c.w = (axis < 3u && ((na >= 0.0f) == is_max)) ? na : 0.0f;   // the corner farthest along n': max where n' >= 0, else min
+	c.cc = (d == 7u || d == 15u) ? cc : -__builtin_inff();
 	return c;
 }
 

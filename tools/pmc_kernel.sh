@@ -8,8 +8,10 @@ root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp && cd "$root"
+# MRT_PMC_PASSES="cycles insts" limits the passes (default: all)
 pass() {
 	name=$1; shift
+	if [ -n "$MRT_PMC_PASSES" ] && [[ " $MRT_PMC_PASSES " != *" $name "* ]]; then return 0; fi
 	rocprofv3 --pmc "$@" --kernel-trace -d "$out/pmc_$name" --output-format csv -- python3 tools/prof_kernel.py "${ARGS[@]}" > "$out/pmc_$name.json" 2> "$out/pmc_$name.err"
 	echo "pass $name done"
 }

@@ -22,12 +22,14 @@ def main():
     ap.add_argument("--kernel", type=int, default=0)
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--count", type=int, default=0)
+    ap.add_argument("--cull", type=int, default=0, help="mrt_options.packet_cull")
+    ap.add_argument("--wg", type=int, default=0, help="mrt_options.packet_wg")
     a = ap.parse_args()
     cfg = synth.CONFIGS[a.config]
     w, h = cfg["grid"]
     scene = capi.Scene(synth.scene_vertices(cfg))
     cam = capi.camera_look(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
-    c = capi.Context(0, kernel=a.kernel, count_visits=a.count)
+    c = capi.Context(0, kernel=a.kernel, count_visits=a.count, packet_cull=a.cull, packet_wg=a.wg)
     scene.upload(c)
     d_hits = c.device_alloc(w * h * 32)
     ms = []
