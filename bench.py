@@ -71,37 +71,93 @@ def parse():
     return ap.parse_args()
 
 
+def one_socket_cpus():
+    """The CPUs of this process's affinity mask that sit on ONE socket (the one holding most of them), their count over
+    all sockets, and the CPU model: SURVEY 8(d) asks for the reference's pool on the cores of one socket, stated."""
+    allowed = sorted(os.sched_getaffinity(0))
+    by_pkg = {}
+    for c in allowed:
+        try:
+            pkg = int(open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id").read())
+        except (OSError, ValueError):
+            pkg = 0
+        by_pkg.setdefault(pkg, []).append(c)
+    pkg = max(by_pkg, key=lambda k: len(by_pkg[k]))
+    model = "unknown"
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return by_pkg[pkg], len(allowed), len(by_pkg), model
+
+
+def source_sha16():
+    """sha256 over the kernel and host sources of libmrt_hip.so (first 16 hex digits): counter passes committed under
+    profiles/ are accepted only for the tree they were taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "messyerraytracer_amd", "csrc")
+    for d, _, files in sorted(os.walk(base)):
+        for f in sorted(files):
+            if f.endswith((".hip", ".h", ".hpp", ".cpp")):
+                h.update(f.encode())
+                h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(cfg, verts):
-    """The reference CPU path timed on this box's host cores (bounded sample).  Checker code, used here only as the
-    reported baseline."""
+    """The reference CPU path timed on this box's host cores (bounded sample): SURVEY 8(d) — the reference's pool shape
+    (persistent helpers, caller + helpers = all allowed cores of one socket, src/dispatch/thread_pool.h:41-55), pinned to
+    that socket, 1 warm-up, median of 5, BVH build excluded, core count and CPU model stated.  Checker code, used here only
+    as the reported baseline."""
     from oracle import pyoracle as po
-    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("MRT_CPU_BASELINE_THREADS", "16")))
+    cpus, n_allowed, n_sockets, model = one_socket_cpus()
+    cores = len(cpus)
+    if os.environ.get("MRT_CPU_BASELINE_THREADS"):
+        cores = min(cores, int(os.environ["MRT_CPU_BASELINE_THREADS"]))
+        cpus = cpus[:cores]
     w, h = cfg["grid"]
-    rows = min(h, max(1, (1 << 24) // w))  # at most 2^24 rays of the grid (C5: a band of 2048 rows)
+    # a bounded sample: ~2 M rays per allowed core, at most 2^24 (one pass of the reference at ~4 Mrays/s per core takes
+    # about half a second; 1 + 5 passes stay well inside the bench's minutes)
+    want = min(1 << 24, max(1 << 20, cores << 21))
+    rows = min(h, max(1, want // w))
     y0 = (h - rows) // 2
     rays = po.grid_rays(cfg["origin"], cfg["forward"], w, h, cfg["fov"], y0, y0 + rows)
-    if po.ref_available():
-        rs = po.RefScene(verts)
-        rs.cast_rays(rays[: rays.shape[0] // 8], n_threads=cores)
-        dts = []
-        for _ in range(3):
-            t0 = time.perf_counter()
-            rs.cast_rays(rays, n_threads=cores)
-            dts.append(time.perf_counter() - t0)
-        dt = sorted(dts)[1]
-        kind = "reference"
-        what = "tinybvh::BVH8_CPU::Intersect (AVX2) under the ThreadPool range split" if po.ref().ref_has_avx2() else \
-            "tinybvh::BVH4_CPU::Intersect (SSE) under the ThreadPool range split"
-        rs.close()
-    else:
-        osc = po.OracleScene(verts)
-        osc.trace(rays[: rays.shape[0] // 8], n_threads=cores)
-        t0 = time.perf_counter()
-        osc.trace(rays, n_threads=cores)
-        dt = time.perf_counter() - t0
-        kind, what = "port", "oracle/mrt_oracle.c scalar BVH2 walk, OpenMP"
+    before = os.sched_getaffinity(0)
+    os.sched_setaffinity(0, cpus)          # the pool's helpers are created below and inherit this mask
+    try:
+        if po.ref_available():
+            rs = po.RefScene(verts)
+            rs.cast_rays(rays, n_threads=cores)   # warm-up: creates the persistent pool, touches the tree
+            dts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                rs.cast_rays(rays, n_threads=cores)
+                dts.append(time.perf_counter() - t0)
+            dt = sorted(dts)[2]
+            kind = "reference"
+            what = "tinybvh::BVH8_CPU::Intersect (AVX2+FMA)" if po.ref().ref_has_avx2() else "tinybvh::BVH4_CPU::Intersect (SSE)"
+            what += " per ray under a persistent range-split pool (chunks = threads, caller runs chunk 0)"
+            rs.close()
+        else:
+            osc = po.OracleScene(verts)
+            osc.trace(rays[: rays.shape[0] // 8], n_threads=cores)
+            dts = []
+            for _ in range(5):
+                t0 = time.perf_counter()
+                osc.trace(rays, n_threads=cores)
+                dts.append(time.perf_counter() - t0)
+            dt = sorted(dts)[2]
+            kind, what = "port", "oracle/mrt_oracle.c scalar BVH2 walk, OpenMP"
+    finally:
+        os.sched_setaffinity(0, before)
     return dict(value=rays.shape[0] / dt / 1e6, unit="Mrays/s", cores=cores, kind=kind,
-                sample=f"rows {y0}..{y0 + rows} of the {w}x{h} grid ({rays.shape[0]} rays), median of 3 passes ({what}; BVH build excluded)")
+                cpu_model=model, cpus_allowed=n_allowed, sockets_in_mask=n_sockets, pinned_to=f"{cores} CPUs of one socket",
+                flags="-O2 -mavx2 -mfma -ffp-contract=off (oracle/Makefile)",
+                sample=f"rows {y0}..{y0 + rows} of the {w}x{h} grid ({rays.shape[0]} rays), 1 warm-up + median of 5 passes ({what}; BVH build excluded)")
 
 
 def digest_of(hits_u8: torch.Tensor, first_index: int = 0) -> dict:
@@ -366,6 +422,7 @@ def main():
                         if token_on else "rccl gather of 32-byte records to rank 0 in %d chunks" % chunks),
                        "frames_in_flight": frames_in_flight, "balance": balance},
         }
+        out["source_sha16"] = source_sha16()   # of messyerraytracer_amd/csrc: what committed counter passes are keyed on
         if verified is not None:
             out["verified"] = verified
         # ---- roofline of the dominant kernel --------------------------------------------------------------------
@@ -373,12 +430,18 @@ def main():
             trace_ms.extend(e0.elapsed_time(e1) for (e0, e1) in events)
             ctx.cast(d_rays.data_ptr(), torch.empty(n_rays * 32, dtype=torch.uint8, device=device), count=n_rays, flags=dev_flags)
             note_kernel()   # (ASYNC casts report no kernel: one blocking cast of the same batch names it)
-        kernel_ms = float(np.sum(trace_ms)) / a.steps          # per step (all chunks), rank 0
+        # per step (all chunks of a step summed), rank 0: the MEDIAN over the timed steps; the mean beside it
+        per_step = np.asarray(trace_ms, dtype=np.float64)
+        per_step = per_step[: (per_step.size // a.steps) * a.steps].reshape(a.steps, -1).sum(axis=1) if per_step.size >= a.steps else per_step
+        kernel_ms = float(np.median(per_step))
+        kernel_ms_mean = float(np.sum(trace_ms)) / a.steps
         kernel_id = sorted(kernels_seen)[0] if kernels_seen else 0
-        kname = capi.kernel_name(kernel_id) + "<any_hit=false>"
+        variant = ctx.last_kernel_variant()     # the instantiation of the last blocking cast, as rocprofv3 spells it
+        kname = variant or (capi.kernel_name(kernel_id) + "<any_hit=false>")
         reads_rays = not (rows_mode or a.mode == "fused")
         roof = {"bound": "hbm", "achieved": None, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": None, "traffic": None,
                 "kernel": kname, "kernels_seen": sorted(capi.kernel_name(k) for k in kernels_seen), "kernel_ms": kernel_ms,
+                "kernel_ms_is": "median over the timed steps of the per-step sum of HIP-event kernel times", "kernel_ms_mean": kernel_ms_mean,
                 "rays_per_step_rank0": rank0_rays}
         # the rows the kernel fetches: counting build of the same kernel on the same batch, now (outside the timed region)
         cctx = capi.Context(local_rank, grid_tile=a.grid_tile, count_visits=1)
@@ -414,10 +477,17 @@ def main():
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
             rec = json.load(open(pmc)).get(a.config, {})
-            if rec and capi.kernel_name(kernel_id).split("<")[0] in (rec.get("kernel") or ""):
+            sha = source_sha16()
+            # accepted only for the very instantiation this run used, taken on this very source tree
+            if rec and not (variant and variant in (rec.get("kernel") or "")):
+                roof["traffic_rejected"] = f"profiles/pmc_traffic.json[{a.config}] is of {rec.get('kernel')!r}, this run used {variant!r}"
+            elif rec and rec.get("source_sha16") != sha:
+                roof["traffic_rejected"] = f"profiles/pmc_traffic.json[{a.config}] was taken on source tree {rec.get('source_sha16')}, this is {sha}"
+            elif rec:
                 scale = rank0_rays / rec.get("rays_per_launch", rank0_rays)
                 roof["traffic"] = rec.get("hbm_bytes_per_launch") * scale if rec.get("hbm_bytes_per_launch") else None
-                roof["traffic_source"] = f"profiles/pmc_traffic.json[{a.config}] ({rec.get('round')}): separate --pmc passes of this command; FETCH_SIZE x2 (gfx950) + WRITE_SIZE"
+                roof["traffic_source"] = (f"profiles/pmc_traffic.json[{a.config}] ({rec.get('round')}, commit {rec.get('commit')}, source {sha}): separate --pmc "
+                                          "passes of this command; FETCH_SIZE x2 (gfx950) + WRITE_SIZE")
                 if roof["traffic"]:
                     roof["hbm_frac_measured"] = roof["traffic"] / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS
                 if rec.get("valu_insts_per_launch"):

@@ -183,7 +183,10 @@ enum {
 	                                      opaque name of the winning triangle valid for this scene upload and
 	                                      for identical uploads on other devices).  mrt_expand_tokens rebuilds
 	                                      the full record from (ray, token) bit for bit: the multi-GPU gather
-	                                      moves 4 bytes per ray instead of 32.  Not with BOOL_OUT.            */
+	                                      moves 4 bytes per ray instead of 32.  Not with BOOL_OUT.  Two-level
+	                                      scenes: a token is TWO words per ray, {triangle, instance} (first
+	                                      word MRT_TOKEN_MISS = miss): mrt_token_bytes() = 8, `hits` is
+	                                      uint32_t[2 * count].                                                */
 	MRT_FLAG_ASYNC          = 1u << 7  /* mrt_cast / mrt_cast_grid with device-resident rays and hits: queue the
 	                                      work on the context's stream and return without waiting (no timing
 	                                      stats).  Order later work on that stream, or mrt_synchronize().
@@ -233,7 +236,8 @@ typedef struct mrt_options {
 	                             round-robin placement, which balances cheap and expensive image regions) */
 	uint32_t stack_override;  /* LDS stack entries per lane (lane kernel), >= what the BVH needs    */
 	uint32_t tile_order;      /* 0: by scene size (Z-order once it exceeds the 256 MB Infinity Cache), 1: tiles in
-	                             row-major order, 2: Z-order inside 16x16-tile super-tiles, 3: inside 32x32-tile ones */
+	                             row-major order, 2: Z-order inside 16x16-tile super-tiles, 3: inside 32x32-tile ones,
+	                             4: column strips per XCD (each XCD's waves on one compact image region; measured neutral) */
 	uint32_t sort_key;        /* 0: origin cell + direction Morton key (default), 1: the reference's
 	                             direction-only key (ray_sort.h:64-76); the order never changes results */
 	uint32_t refill;          /* persistent lane kernel: refill a wave when this many lanes are idle (default 16) */
@@ -245,8 +249,9 @@ typedef struct mrt_options {
 	                             256 MB of nodes + triangles: wave slots refill one by one; 256 above: the four waves of a
 	                             workgroup walk neighbouring tiles through one scalar cache) */
 	uint32_t packet_cull;     /* MRT_KERNEL_PACKET_DUAL: packet-level frustum culling (a child box wholly outside the pyramid of
-	                             a packet's rays is skipped for all 128 of them): 0 = library default (off: it removes 12 % of
-	                             the vector instructions and costs 8 % of time), 1 = off, 2 = on */
+	                             a packet's rays is skipped for all 128 of them; packets that are not a pinhole bundle never
+	                             cull): 0 = library default (on since round 3: 14 % fewer vector instructions, C3 1.5 %, C5 3 %
+	                             faster), 1 = off, 2 = on */
 	uint32_t reserved[1];
 } mrt_options;
 
@@ -411,6 +416,8 @@ int mrt_cast_tiled(mrt_ctx *ctx, const mrt_ray32 *d_rays, mrt_hit32 *d_hits,
  * `hip_stream` (hipStream_t as void*; 0 = the context's stream) without waiting. */
 int mrt_expand_tokens(mrt_ctx *ctx, const void *d_rays, const uint32_t *d_tokens, void *d_hits,
 		uint64_t count, uint32_t flags, void *hip_stream);
+/* Bytes per hit token of the scene this context holds: 4 (flat scene), 8 (two-level scene); 0 for a null context. */
+uint32_t mrt_token_bytes(mrt_ctx *ctx);
 /* Same for rows [y0,y1) of a camera grid (tokens from mrt_cast_grid, on this or another device). */
 int mrt_expand_grid_tokens(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t grid_h,
 		uint32_t y0, uint32_t y1, const uint32_t *d_tokens, mrt_hit32 *d_hits, void *hip_stream);
@@ -420,6 +427,11 @@ int mrt_morton_keys(mrt_ctx *ctx, const mrt_ray32 *d_rays, uint64_t count, uint3
 
 /* ---- stats / device memory helpers ---------------------------------------- */
 int mrt_get_stats(mrt_ctx *ctx, mrt_stats *out);
+/* The template instantiation that did the work of the last blocking cast, spelled as rocprofv3 prints kernel names
+ * (e.g. "trace_packet_rows_kernel<false, false, 2, 64, true>"); "" before the first cast and after an ASYNC one.  No
+ * reference counterpart (the reference prints its pipeline choice, gpu_ray_caster.cpp:654-671); bench.py uses it to
+ * accept committed counter passes only for the very kernel a run used. */
+const char *mrt_last_kernel_variant(mrt_ctx *ctx);
 int mrt_device_alloc(mrt_ctx *ctx, size_t bytes, void **d_ptr);
 int mrt_device_free(mrt_ctx *ctx, void *d_ptr);
 int mrt_memcpy_h2d(mrt_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);

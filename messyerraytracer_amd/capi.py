@@ -30,8 +30,8 @@ SYMBOLS = [
     "mrt_synchronize", "mrt_make_triangles", "mrt_pack_host_triangles", "mrt_bvh2_build", "mrt_bvh2_save", "mrt_bvh2_load", "mrt_upload_scene",
     "mrt_build_scene_device", "mrt_flatten_instances", "mrt_build_instanced_scene_device", "mrt_upload_two_level_scene", "mrt_update_instances", "mrt_is_available", "mrt_scene_info", "mrt_cast", "mrt_submit", "mrt_collect", "mrt_has_pending",
     "mrt_camera_look", "mrt_camera_perspective", "mrt_camera_orthographic", "mrt_generate_grid", "mrt_cast_grid", "mrt_cast_tiled", "mrt_expand_tokens",
-    "mrt_expand_grid_tokens", "mrt_morton_keys",
-    "mrt_kernel_name", "mrt_struct_size", "mrt_get_stats", "mrt_device_alloc", "mrt_device_free", "mrt_memcpy_h2d", "mrt_memcpy_d2h",
+    "mrt_expand_grid_tokens", "mrt_token_bytes", "mrt_morton_keys",
+    "mrt_kernel_name", "mrt_struct_size", "mrt_get_stats", "mrt_last_kernel_variant", "mrt_device_alloc", "mrt_device_free", "mrt_memcpy_h2d", "mrt_memcpy_d2h",
     "mrt_group_create", "mrt_group_destroy", "mrt_group_size", "mrt_group_context", "mrt_group_last_error", "mrt_group_row_block",
     "mrt_group_upload_scene", "mrt_group_upload_two_level_scene", "mrt_group_cast_grid",
 ]
@@ -87,6 +87,10 @@ def load():
     L.mrt_struct_size.argtypes = [C.c_uint32]
     L.mrt_kernel_name.restype = C.c_char_p
     L.mrt_kernel_name.argtypes = [C.c_uint32]
+    L.mrt_token_bytes.restype = C.c_uint32
+    L.mrt_token_bytes.argtypes = [C.c_void_p]
+    L.mrt_last_kernel_variant.restype = C.c_char_p
+    L.mrt_last_kernel_variant.argtypes = [C.c_void_p]
     L.mrt_create.argtypes = [C.c_int, C.POINTER(Options), C.POINTER(C.c_void_p)]
     L.mrt_destroy.argtypes = [C.c_void_p]
     L.mrt_destroy.restype = None
@@ -348,7 +352,7 @@ class Context:
             if flags & FLAG_BOOL_OUT:
                 hits = np.zeros(count, dtype=np.uint8)
             elif flags & FLAG_TOKEN_OUT:
-                hits = np.zeros(count, dtype=np.uint32)
+                hits = self._token_array(count)
             elif flags & FLAG_HOST_LAYOUT:
                 hits = np.zeros(count, dtype=T.HOST_HIT44)
             else:
@@ -373,7 +377,7 @@ class Context:
             if flags & FLAG_BOOL_OUT:
                 hits = np.zeros(count, dtype=np.uint8)
             elif flags & FLAG_TOKEN_OUT:
-                hits = np.zeros(count, dtype=np.uint32)
+                hits = self._token_array(count)
             elif flags & FLAG_HOST_LAYOUT:
                 hits = np.zeros(count, dtype=T.HOST_HIT44)
             else:
@@ -391,7 +395,7 @@ class Context:
         y1 = grid_h if y1 is None else y1
         n = grid_w * (y1 - y0)
         if hits is None:
-            hits = np.zeros(n, dtype=np.uint8 if (flags & FLAG_BOOL_OUT) else (np.uint32 if (flags & FLAG_TOKEN_OUT) else T.HIT32))
+            hits = np.zeros(n, dtype=np.uint8) if (flags & FLAG_BOOL_OUT) else (self._token_array(n) if (flags & FLAG_TOKEN_OUT) else np.zeros(n, dtype=T.HIT32))
         self._chk(self.L.mrt_cast_grid(self.h, C.byref(cam), grid_w, grid_h, y0, y1, _ptr(hits), query_mask, mode, flags))
         return hits
 
@@ -414,6 +418,19 @@ class Context:
         s = Stats()
         self._chk(self.L.mrt_get_stats(self.h, C.byref(s)))
         return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def _token_array(self, count):
+        """host array for `count` hit tokens: uint32[count] (flat scene) or uint32[count, 2] (two-level: {triangle, instance})"""
+        words = self.token_bytes() // 4
+        return np.zeros(count if words == 1 else (count, words), dtype=np.uint32)
+
+    def token_bytes(self) -> int:
+        """Bytes per hit token (MRT_FLAG_TOKEN_OUT): 4 for a flat scene, 8 ({triangle, instance}) for a two-level one."""
+        return int(self.L.mrt_token_bytes(self.h))
+
+    def last_kernel_variant(self) -> str:
+        """The instantiation that ran the last blocking cast, as rocprofv3 spells kernel names."""
+        return self.L.mrt_last_kernel_variant(self.h).decode()
 
     def device_alloc(self, nbytes: int) -> int:
         p = C.c_void_p()

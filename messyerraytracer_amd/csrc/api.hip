@@ -21,6 +21,7 @@
 
 namespace mrt {
 hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream);
+const char *last_trace_variant();
 hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t stream);
 hipError_t launch_build_rows4(const Dev4Node *nodes4, const TriHot *hot, const TriCold *cold, uint32_t n_nodes4, uint32_t n_tris,
 		void *rows, hipStream_t stream);
@@ -76,6 +77,7 @@ struct mrt_ctx {
 	// small host-array casts (RayDispatcher::cast_ray / any_hit: one ray; tiles of a few hundred rays): rays and hits go
 	// through two pinned, device-mapped buffers instead of two DMA copies (mrt_cast)
 	void *h_small_in = nullptr, *d_small_in = nullptr, *h_small_out = nullptr, *d_small_out = nullptr;
+	char queued_variant[96] = "", queued_alt_variant[96] = "", last_variant[96] = ""; // instantiation names (mrt_last_kernel_variant)
 	uint32_t queued_kernel = 0, queued_alt_kernel = 0; bool queued_detect = false; // what the last enqueue_cast put on the stream
 	// host-array pipeline (cast_host_pipelined): copy streams and per-chunk events, created on first use
 	hipStream_t up_stream = nullptr, dn_stream = nullptr;
@@ -141,17 +143,19 @@ void free_scene(mrt_ctx *ctx)
 }
 
 size_t ray_stride(uint32_t flags) { return (flags & MRT_FLAG_HOST_LAYOUT) ? sizeof(mrt_host_ray60) : sizeof(mrt_ray32); }
-size_t hit_stride(uint32_t flags, int mode)
+// hit tokens: 4 bytes (flat scenes: the winning triangle's slot), 8 for a two-level scene ({triangle slot, instance row})
+size_t token_bytes(const mrt_ctx *ctx) { return ctx->two_level ? 8 : 4; }
+size_t hit_stride(const mrt_ctx *ctx, uint32_t flags, int mode)
 {
 	if ((flags & MRT_FLAG_BOOL_OUT) && mode == MRT_MODE_ANY_HIT) return 1;
-	if (flags & MRT_FLAG_TOKEN_OUT) return sizeof(uint32_t);
+	if (flags & MRT_FLAG_TOKEN_OUT) return token_bytes(ctx);
 	return (flags & MRT_FLAG_HOST_LAYOUT) ? sizeof(mrt_host_hit44) : sizeof(mrt_hit32);
 }
 
-uint32_t out_format(uint32_t flags, int mode)
+uint32_t out_format(const mrt_ctx *ctx, uint32_t flags, int mode)
 {
 	if ((flags & MRT_FLAG_BOOL_OUT) && mode == MRT_MODE_ANY_HIT) return mrt::OUT_BOOL8;
-	if (flags & MRT_FLAG_TOKEN_OUT) return mrt::OUT_TOKEN4;
+	if (flags & MRT_FLAG_TOKEN_OUT) return ctx->two_level ? mrt::OUT_TOKEN8 : mrt::OUT_TOKEN4;
 	return (flags & MRT_FLAG_HOST_LAYOUT) ? mrt::OUT_HOST44 : mrt::OUT_HIT32;
 }
 
@@ -160,6 +164,7 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 	std::memset(&p, 0, sizeof(p));
 	p.nodes = ctx->d_nodes; p.nodes4 = ctx->d_nodes4; p.nodes8 = ctx->d_nodes8; p.leaf_box = ctx->d_leaf_box; p.instances = ctx->d_instances; p.tri_hot = ctx->d_hot; p.tri_cold = ctx->d_cold; p.row_array = ctx->d_rows; p.row_array4 = ctx->d_rows4; p.tri_unit_base4 = 2u * ctx->n_nodes4;
 	p.stack_depth = ctx->stack_depth; p.n_tris = ctx->n_tris; p.n_nodes = ctx->n_nodes;
+	p.n_instances = ctx->two_level ? ctx->two_level->n_inst : 0u;
 	if (ctx->opts.stack_override >= ctx->depth && ctx->opts.stack_override <= 64) p.stack_depth = ctx->opts.stack_override;
 	p.counters = ctx->d_counters;
 	p.xcd_swizzle = ctx->opts.xcd_swizzle ? 1 : 0;
@@ -170,9 +175,10 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 	const size_t scene_bytes = (size_t)ctx->n_nodes * sizeof(mrt::DevNode) + (size_t)ctx->n_tris * (sizeof(mrt::TriHot) + sizeof(mrt::TriCold));
 	p.tile_order = ctx->opts.tile_order == 2 || (ctx->opts.tile_order == 0 && scene_bytes > (size_t)256 << 20) ? 1u : 0u;
 	if (ctx->opts.tile_order == 3) p.tile_order = 2u; // 32x32-tile super-tiles (C5: 23.3 against 23.5 ms; not the default)
+	if (ctx->opts.tile_order == 4) p.tile_order = 3u; // column strips per XCD (kernels.hip, xcd_strips)
 	p.extra_lds = ctx->opts.extra_lds <= 60000u ? ctx->opts.extra_lds : 60000u;
 	p.count_mode = ctx->opts.count_visits;
-	p.rows_cull = ctx->opts.packet_cull == 2u ? 1u : 0u; // off by default: the test's vector loads cost more than the skipped slab tests save (packet_rows_kernel.h)
+	p.rows_cull = ctx->opts.packet_cull == 1u ? 0u : 1u; // on by default since round 3 (one lane-row load a step ahead + DPP reduction: C3 -1.5 %, C5 -3 %; packet_rows_kernel.h)
 	p.scene_abs_max = 0.0f;
 	for (int c = 0; c < 3; c++) p.scene_abs_max = std::fmax(p.scene_abs_max, std::fmax(std::fabs(ctx->bounds_lo[c]), std::fabs(ctx->bounds_hi[c])));
 	p.rows_wg = ctx->opts.packet_wg == 64u || ctx->opts.packet_wg == 256u ? ctx->opts.packet_wg : (scene_bytes > (size_t)256 << 20 ? 256u : 64u);
@@ -272,7 +278,7 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 	if (!persistent || !can_count) {
 		p.kernel = ctx->two_level ? mrt::MRT_KERNEL_TWO_LEVEL : MRT_KERNEL_LANE;
 		HIP_TRY(ctx, mrt::launch_trace(p, any_hit, ctx->opts.count_visits != 0, ctx->stream));
-		ctx->queued_kernel = p.kernel;
+		ctx->queued_kernel = p.kernel; std::snprintf(ctx->queued_variant, sizeof(ctx->queued_variant), "%s", mrt::last_trace_variant());
 		return MRT_OK;
 	}
 	const uint32_t lds_depth = ctx->opts.stack_override >= 4 && ctx->opts.stack_override <= 64 ? ctx->opts.stack_override : 16u;
@@ -295,7 +301,7 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 	HIP_TRY(ctx, mrt::launch_trace_persistent(p, next_ray, ovf, lds_depth, ctx->opts.refill ? ctx->opts.refill : 16u,
 			ctx->opts.leaf_wait ? ctx->opts.leaf_wait : (wide8 ? 8u : 16u), (uint32_t)blocks, any_hit,
 			ctx->opts.count_visits != 0 && !ctx->two_level, ctx->stream));
-	ctx->queued_kernel = p.kernel;
+	ctx->queued_kernel = p.kernel; std::snprintf(ctx->queued_variant, sizeof(ctx->queued_variant), "%s", mrt::last_trace_variant());
 	return MRT_OK;
 }
 
@@ -307,8 +313,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	if (mode != MRT_MODE_NEAREST && mode != MRT_MODE_ANY_HIT) return fail(ctx, MRT_ERR_INVALID, "bad mode");
 	if ((flags & MRT_FLAG_BOOL_OUT) && mode != MRT_MODE_ANY_HIT) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT needs any-hit mode");
 	if ((flags & MRT_FLAG_BOOL_OUT) && (flags & MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT and TOKEN_OUT exclude each other");
-	if (ctx->two_level && (flags & MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_UNSUPPORTED, "hit tokens need a flat scene");
-	const size_t rs = ray_stride(flags), hs = hit_stride(flags, mode);
+	const size_t rs = ray_stride(flags), hs = hit_stride(ctx, flags, mode);
 	int rc;
 	const void *d_rays = rays;
 	ctx->stats.last_h2d_ms = ctx->stats.last_d2h_ms = ctx->stats.last_sort_ms = 0.0f;
@@ -328,7 +333,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	base_params(ctx, p);
 	p.rays = d_rays; p.hits = d_hits; p.count = count; p.query_mask = query_mask;
 	p.in_fmt = (flags & MRT_FLAG_HOST_LAYOUT) ? mrt::IN_HOST60 : mrt::IN_RAY32;
-	p.out_fmt = out_format(flags, mode);
+	p.out_fmt = out_format(ctx, flags, mode);
 	p.lane_map = mrt::MAP_LINEAR;
 	const uint32_t thr = ctx->opts.sort_threshold ? ctx->opts.sort_threshold : 256u; // MIN_BATCH_FOR_SORTING
 	const bool sort = !(flags & MRT_FLAG_COHERENT) && (count >= thr || (flags & MRT_FLAG_FORCE_SORT));
@@ -360,11 +365,13 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 		p.skip_flag = p.auto_grid + 3; p.skip_when = 1u;
 		HIP_TRY(ctx, mrt::launch_trace(p, any, false, ctx->stream));
 		const uint32_t packet_kernel = p.kernel;
+		char packet_variant[96]; std::snprintf(packet_variant, sizeof(packet_variant), "%s", mrt::last_trace_variant());
 		mrt::TraceParams lp = p;
 		lp.kernel = MRT_KERNEL_LANE; lp.lane_map = mrt::MAP_LINEAR; lp.auto_grid = nullptr; lp.skip_when = 0u;
 		if ((rc = launch_lane(ctx, lp, count, any, count >= 65536))) return rc; // (a two-level scene: its own lane kernels)
 		ctx->queued_alt_kernel = ctx->queued_kernel; // what launch_lane queued: runs if the batch is judged incoherent
-		ctx->queued_kernel = packet_kernel;
+		std::snprintf(ctx->queued_alt_variant, sizeof(ctx->queued_alt_variant), "%s", ctx->queued_variant);
+		ctx->queued_kernel = packet_kernel; std::snprintf(ctx->queued_variant, sizeof(ctx->queued_variant), "%s", packet_variant);
 	} else {
 		// large incoherent batches: resident waves that pull rays from a counter (no counting variant)
 		const bool persistent = p.lane_map == mrt::MAP_LINEAR &&
@@ -374,7 +381,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 			if ((rc = launch_lane(ctx, p, count, any, persistent))) return rc;
 		} else {
 			HIP_TRY(ctx, mrt::launch_trace(p, any, ctx->opts.count_visits != 0, ctx->stream));
-			ctx->queued_kernel = p.kernel;
+			ctx->queued_kernel = p.kernel; std::snprintf(ctx->queued_variant, sizeof(ctx->queued_variant), "%s", mrt::last_trace_variant());
 		}
 	}
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
@@ -396,7 +403,9 @@ int finish_timing(mrt_ctx *ctx, bool h2d, bool sorted, bool d2h)
 	// which kernel did the work: the stream has been waited for, so detect_grid_kernel's words are in h_auto
 	ctx->stats.detected_grid_w = ctx->queued_detect ? ctx->h_auto[0] : 0u;
 	ctx->stats.reserved = ctx->queued_detect ? ctx->h_auto[3] : 0u; // 1: the "coherent" batch was judged incoherent
-	ctx->stats.last_kernel = (ctx->queued_detect && ctx->queued_alt_kernel && ctx->h_auto[3]) ? ctx->queued_alt_kernel : ctx->queued_kernel;
+	const bool alt_ran = ctx->queued_detect && ctx->queued_alt_kernel && ctx->h_auto[3];
+	ctx->stats.last_kernel = alt_ran ? ctx->queued_alt_kernel : ctx->queued_kernel;
+	std::snprintf(ctx->last_variant, sizeof(ctx->last_variant), "%s", alt_ran ? ctx->queued_alt_variant : ctx->queued_variant);
 	if (ctx->opts.count_visits) {
 		unsigned long long c[mrt::kNumCounters];
 		HIP_TRY(ctx, hipMemcpy(c, ctx->d_counters, sizeof(c), hipMemcpyDeviceToHost));
@@ -419,7 +428,7 @@ constexpr uint64_t kPipeChunk = 1ull << 20;
 
 int cast_host_pipelined(mrt_ctx *ctx, const void *rays, void *hits, uint64_t count, uint32_t query_mask, int mode, uint32_t flags)
 {
-	const size_t rs = ray_stride(flags), hs = hit_stride(flags, mode);
+	const size_t rs = ray_stride(flags), hs = hit_stride(ctx, flags, mode);
 	const uint32_t n_chunks = (uint32_t)((count + kPipeChunk - 1) / kPipeChunk);
 	int rc;
 	if ((rc = ensure(ctx, ctx->rays, count * rs)) || (rc = ensure(ctx, ctx->hits, count * hs))) return rc;
@@ -951,7 +960,7 @@ int mrt_cast(mrt_ctx *ctx, const void *rays, void *hits, uint64_t count, uint32_
 	// writes the records to, pinned host memory mapped into the device (one ray: 85 -> 55 us per blocking call,
 	// tools/bench_latency.py).  The same kernels, the same records.
 	if (!hits_dev && !(flags & (MRT_FLAG_RAYS_ON_DEVICE | MRT_FLAG_ASYNC)) && count <= kSmallCast && !ctx->opts.count_visits) {
-		const size_t rs_ = ray_stride(flags), hs_ = hit_stride(flags, mode);
+		const size_t rs_ = ray_stride(flags), hs_ = hit_stride(ctx, flags, mode);
 		if (!ctx->h_small_in) {
 			if (hipHostMalloc(&ctx->h_small_in, kSmallCast * 64, hipHostMallocMapped) != hipSuccess ||
 					hipHostMalloc(&ctx->h_small_out, kSmallCast * 64, hipHostMallocMapped) != hipSuccess ||
@@ -976,7 +985,7 @@ int mrt_cast(mrt_ctx *ctx, const void *rays, void *hits, uint64_t count, uint32_
 	if (rc) return rc;
 	if (flags & MRT_FLAG_ASYNC) { ctx->stats.last_kernel = 0; return MRT_OK; } // queued on the context's stream; no timing
 	if (!hits_dev) {
-		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, count * hit_stride(flags, mode), hipMemcpyDeviceToHost, ctx->stream));
+		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, count * hit_stride(ctx, flags, mode), hipMemcpyDeviceToHost, ctx->stream));
 		HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
 	}
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1007,7 +1016,7 @@ int mrt_collect(mrt_ctx *ctx, void *hits, uint64_t count)
 	if (!hits) return fail(ctx, MRT_ERR_INVALID, "null hits");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	const uint64_t n = count < ctx->pending_count ? count : ctx->pending_count; // cpp:573
-	HIP_TRY(ctx, hipMemcpyAsync(hits, ctx->pending_dev_hits, n * hit_stride(ctx->pending_flags, ctx->pending_mode),
+	HIP_TRY(ctx, hipMemcpyAsync(hits, ctx->pending_dev_hits, n * hit_stride(ctx, ctx->pending_flags, ctx->pending_mode),
 			hipMemcpyDeviceToHost, ctx->stream));
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -1052,26 +1061,25 @@ int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t
 	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded");
 	if (ctx->pending) return fail(ctx, MRT_ERR_PENDING, "collect the pending dispatch first");
 	if (flags & MRT_FLAG_HOST_LAYOUT) return fail(ctx, MRT_ERR_UNSUPPORTED, "grid casts write packed hits");
-	if (ctx->two_level && (flags & MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_UNSUPPORTED, "hit tokens need a flat scene");
 	if ((flags & MRT_FLAG_BOOL_OUT) && (flags & MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT and TOKEN_OUT exclude each other");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	mrt::TraceParams p;
 	int rc = grid_params(ctx, cam, grid_w, grid_h, y0, y1, p);
 	if (rc) return rc;
 	if (p.count == 0) return MRT_OK;
-	const size_t hs = hit_stride(flags, mode);
+	const size_t hs = hit_stride(ctx, flags, mode);
 	const bool hits_dev = (flags & MRT_FLAG_HITS_ON_DEVICE) != 0;
 	if ((flags & MRT_FLAG_ASYNC) && !hits_dev) return fail(ctx, MRT_ERR_INVALID, "ASYNC needs device-resident hits");
 	void *d_hits = hits;
 	if (!hits_dev) { if ((rc = ensure(ctx, ctx->hits, p.count * hs))) return rc; d_hits = ctx->hits.ptr; }
 	p.hits = d_hits; p.query_mask = query_mask;
-	p.out_fmt = out_format(flags, mode);
+	p.out_fmt = out_format(ctx, flags, mode);
 	p.lane_map = ctx->opts.grid_tile == 1 ? mrt::MAP_LINEAR : mrt::MAP_TILE8X8;
 	p.kernel = pick_kernel(ctx, true, p.count);
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
-	ctx->queued_kernel = p.kernel; ctx->queued_alt_kernel = 0; ctx->queued_detect = false;
+	ctx->queued_kernel = p.kernel; std::snprintf(ctx->queued_variant, sizeof(ctx->queued_variant), "%s", mrt::last_trace_variant()); ctx->queued_alt_kernel = 0; ctx->queued_detect = false;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
 	if (flags & MRT_FLAG_ASYNC) { ctx->stats.rays_cast += p.count; ctx->stats.last_kernel = 0; return MRT_OK; }
 	if (!hits_dev) {
@@ -1103,7 +1111,7 @@ int mrt_cast_tiled(mrt_ctx *ctx, const mrt_ray32 *d_rays, mrt_hit32 *d_hits,
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
-	ctx->queued_kernel = p.kernel; ctx->queued_alt_kernel = 0; ctx->queued_detect = false;
+	ctx->queued_kernel = p.kernel; std::snprintf(ctx->queued_variant, sizeof(ctx->queued_variant), "%s", mrt::last_trace_variant()); ctx->queued_alt_kernel = 0; ctx->queued_detect = false;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	ctx->stats.last_kernel_launches = 1; ctx->stats.rays_cast += p.count;
@@ -1116,7 +1124,6 @@ int mrt_expand_tokens(mrt_ctx *ctx, const void *d_rays, const uint32_t *d_tokens
 {
 	if (!ctx) return MRT_ERR_INVALID;
 	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded");
-	if (ctx->two_level) return fail(ctx, MRT_ERR_UNSUPPORTED, "hit tokens need a flat scene");
 	if (count == 0) return MRT_OK;
 	if (!d_rays || !d_tokens || !d_hits) return fail(ctx, MRT_ERR_INVALID, "null rays / tokens / hits");
 	if (flags & (MRT_FLAG_BOOL_OUT | MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_INVALID, "tokens expand to hit records only");
@@ -1135,7 +1142,6 @@ int mrt_expand_grid_tokens(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w,
 {
 	if (!ctx) return MRT_ERR_INVALID;
 	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded");
-	if (ctx->two_level) return fail(ctx, MRT_ERR_UNSUPPORTED, "hit tokens need a flat scene");
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	mrt::TraceParams p;
 	int rc = grid_params(ctx, cam, grid_w, grid_h, y0, y1, p);
@@ -1154,6 +1160,16 @@ int mrt_morton_keys(mrt_ctx *ctx, const mrt_ray32 *d_rays, uint64_t count, uint3
 	HIP_TRY(ctx, mrt::launch_morton_keys(d_rays, mrt::IN_RAY32, count, d_keys, nullptr, ctx->stream));
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	return MRT_OK;
+}
+
+uint32_t mrt_token_bytes(mrt_ctx *ctx)
+{
+	return ctx ? (uint32_t)token_bytes(ctx) : 0u;
+}
+
+const char *mrt_last_kernel_variant(mrt_ctx *ctx)
+{
+	return ctx ? ctx->last_variant : "";
 }
 
 int mrt_get_stats(mrt_ctx *ctx, mrt_stats *out)

@@ -9,8 +9,8 @@
 // generation, mrt_cast_grid) and writes 4-byte hit tokens; the tokens travel to device 0 as peer copies (xGMI:
 // point-to-point, each peer over its own link, no ring), and device 0 rebuilds the 32-byte records with
 // mrt_expand_grid_tokens from its own copy of the scene — bit-identical to what the casts would have stored
-// (tests/test_parity_gpu.py::test_hit_tokens_expand_to_identical_records).  Any-hit bool output and two-level scenes
-// (no tokens) send what the casts wrote.  The host only queues work: casts are MRT_FLAG_ASYNC, copies are
+// (tests/test_parity_gpu.py::test_hit_tokens_expand_to_identical_records).  Two-level scenes travel as 8-byte tokens
+// {triangle, instance} (mrt_token_bytes); any-hit bool output sends what the casts wrote.  The host only queues work: casts are MRT_FLAG_ASYNC, copies are
 // hipMemcpyPeerAsync on the sending device's stream, device 0's stream waits on one event per peer.
 #include <cstdio>
 #include <cstring>
@@ -23,7 +23,10 @@ struct mrt_group {
 	std::vector<mrt_ctx *> ctx;
 	std::vector<int> device;
 	std::vector<hipStream_t> stream;
-	std::vector<hipEvent_t> done;          // per member: its block is on device 0
+	std::vector<hipEvent_t> done;          // per member (spare; the chunked cast uses the per-chunk events below)
+	std::vector<hipStream_t> copy_stream;  // per member > 0: its peer copies (beside its next trace)
+	std::vector<std::vector<hipEvent_t>> traced, copied; // per member and chunk: the chunk is traced / has arrived on device 0
+	hipStream_t xstream = nullptr;         // device 0: record rebuilds + the final copy, beside member 0's tracing
 	std::vector<void *> block;             // per member: what its cast writes (tokens, records or bools), on its device
 	std::vector<size_t> block_cap;
 	void *staged = nullptr; size_t staged_cap = 0;   // device 0: everybody's tokens, row-major
@@ -105,6 +108,7 @@ int mrt_group_create(int n_devices, const int *device_ordinals, const mrt_option
 		}
 		g->ctx.push_back(c); g->device.push_back(dev); g->stream.push_back(s); g->done.push_back(e);
 		g->block.push_back(nullptr); g->block_cap.push_back(0);
+		g->copy_stream.push_back(nullptr); g->traced.emplace_back(); g->copied.emplace_back();
 	}
 	// peers may write device 0's memory directly (xGMI); without it the copies are staged by the runtime
 	for (size_t i = 1; i < g->device.size(); i++) {
@@ -127,10 +131,14 @@ void mrt_group_destroy(mrt_group *g)
 		if (g->block[i]) (void)hipFree(g->block[i]);
 		mrt_destroy(g->ctx[i]);            // (waits for its stream, which it does not own)
 		if (g->done[i]) (void)hipEventDestroy(g->done[i]);
+		for (hipEvent_t e : g->traced[i]) (void)hipEventDestroy(e);
+		for (hipEvent_t e : g->copied[i]) (void)hipEventDestroy(e);
+		if (g->copy_stream[i]) { (void)hipStreamSynchronize(g->copy_stream[i]); (void)hipStreamDestroy(g->copy_stream[i]); }
 		if (g->stream[i]) (void)hipStreamDestroy(g->stream[i]);
 	}
 	if (!g->device.empty()) {
 		(void)hipSetDevice(g->device[0]);
+		if (g->xstream) { (void)hipStreamSynchronize(g->xstream); (void)hipStreamDestroy(g->xstream); }
 		if (g->staged) (void)hipFree(g->staged);
 		if (g->image) (void)hipFree(g->image);
 	}
@@ -171,6 +179,13 @@ int mrt_group_upload_two_level_scene(mrt_group *g, const float *verts9, uint32_t
 // records (mrt_hit32; uint8 with MRT_FLAG_BOOL_OUT in any-hit mode), row-major, on the host or — with
 // MRT_FLAG_HITS_ON_DEVICE — in device 0's memory.  Blocking.  Equals mrt_cast_grid of the whole grid on one device,
 // byte for byte.
+//
+// Every member's row block is cut into kGroupChunks chunks, and three things run beside each other: the member traces
+// chunk c + 1 on its own stream while chunk c travels to device 0 on the member's copy stream (hipMemcpyPeerAsync, each
+// peer over its own xGMI link), and device 0 rebuilds the records of every chunk that has arrived on a side stream of
+// its own beside its own tracing (as sharded.ShardedGrid does per rank).  The host only queues work and waits once.
+static constexpr uint32_t kGroupChunks = 4;
+
 int mrt_group_cast_grid(mrt_group *g, const mrt_camera *cam, uint32_t grid_w, uint32_t grid_h, void *hits, uint32_t query_mask,
 		int mode, uint32_t flags)
 {
@@ -180,9 +195,9 @@ int mrt_group_cast_grid(mrt_group *g, const mrt_camera *cam, uint32_t grid_w, ui
 	if ((flags & MRT_FLAG_BOOL_OUT) && mode != MRT_MODE_ANY_HIT) return gfail(g, MRT_ERR_INVALID, "BOOL_OUT needs any-hit mode");
 	const uint32_t n = (uint32_t)g->ctx.size();
 	const bool bools = (flags & MRT_FLAG_BOOL_OUT) != 0;
-	const bool tokens = !bools && !g->two_level && n > 1;      // what travels: 4-byte tokens, else what the cast writes
+	const bool tokens = !bools && n > 1;                        // what travels: hit tokens (4 bytes; 8 for a two-level scene), else the bools
 	const size_t out_stride = bools ? 1 : sizeof(mrt_hit32);
-	const size_t wire_stride = tokens ? 4 : out_stride;
+	const size_t wire_stride = tokens ? mrt_token_bytes(g->ctx[0]) : out_stride;
 	const size_t total = (size_t)grid_w * grid_h;
 	const bool on_device = (flags & MRT_FLAG_HITS_ON_DEVICE) != 0;
 	int rc;
@@ -191,44 +206,61 @@ int mrt_group_cast_grid(mrt_group *g, const mrt_camera *cam, uint32_t grid_w, ui
 		if ((rc = grow(g, g->device[0], &g->image, &g->image_cap, total * out_stride))) return rc;
 		d_out = g->image;
 	}
-	if (tokens && (rc = grow(g, g->device[0], &g->staged, &g->staged_cap, total * 4))) return rc;
+	if (tokens && (rc = grow(g, g->device[0], &g->staged, &g->staged_cap, total * wire_stride))) return rc;
 	char *dst0 = (char *)(tokens ? g->staged : d_out);          // device 0: where the blocks land
 	const uint32_t cast_flags = MRT_FLAG_HITS_ON_DEVICE | MRT_FLAG_ASYNC | (tokens ? MRT_FLAG_TOKEN_OUT : 0u) | (bools ? MRT_FLAG_BOOL_OUT : 0u);
-	// 1. every member traces its rows (queued; the host does not wait)
+	const uint32_t chunks = n > 1 ? kGroupChunks : 1u;
+	// device 0's side stream: record rebuilds and the final copy (created on first use)
+	GHIP(g, hipSetDevice(g->device[0]));
+	if (!g->xstream) GHIP(g, hipStreamCreateWithFlags(&g->xstream, hipStreamNonBlocking));
 	for (uint32_t r = 0; r < n; r++) {
 		uint32_t y0, y1;
 		mrt_group_row_block(r, n, grid_h, &y0, &y1);
 		if (y1 == y0) continue;
-		const size_t off = (size_t)y0 * grid_w * wire_stride, bytes = (size_t)(y1 - y0) * grid_w * wire_stride;
-		void *out = dst0 + off;                                 // member 0 writes in place
+		char *block = dst0 + (size_t)y0 * grid_w * wire_stride;  // member 0 writes in place
 		if (r > 0) {
-			if ((rc = grow(g, g->device[r], &g->block[r], &g->block_cap[r], bytes))) return rc;
-			out = g->block[r];
+			if ((rc = grow(g, g->device[r], &g->block[r], &g->block_cap[r], (size_t)(y1 - y0) * grid_w * wire_stride))) return rc;
+			block = (char *)g->block[r];
 		}
-		rc = mrt_cast_grid(g->ctx[r], cam, grid_w, grid_h, y0, y1, out, query_mask, mode, cast_flags);
-		if (rc) return gfail_ctx(g, rc, (int)r);
-		if (r > 0) { // 2. its block to device 0, behind the cast on the member's own stream
+		GHIP(g, hipSetDevice(g->device[r]));
+		if (r > 0 && !g->copy_stream[r]) GHIP(g, hipStreamCreateWithFlags(&g->copy_stream[r], hipStreamNonBlocking));
+		while (g->traced[r].size() < chunks) { hipEvent_t e; GHIP(g, hipEventCreateWithFlags(&e, hipEventDisableTiming)); g->traced[r].push_back(e); }
+		while (g->copied[r].size() < chunks) { hipEvent_t e; GHIP(g, hipEventCreateWithFlags(&e, hipEventDisableTiming)); g->copied[r].push_back(e); }
+		for (uint32_t c = 0; c < chunks; c++) {
+			uint32_t c0, c1;
+			mrt_group_row_block(c, chunks, y1 - y0, &c0, &c1);
+			if (c1 == c0) continue;
+			const size_t off = (size_t)c0 * grid_w * wire_stride, bytes = (size_t)(c1 - c0) * grid_w * wire_stride;
+			// 1. the member traces the chunk (queued on its stream; the host does not wait)
+			rc = mrt_cast_grid(g->ctx[r], cam, grid_w, grid_h, y0 + c0, y0 + c1, block + off, query_mask, mode, cast_flags);
+			if (rc) return gfail_ctx(g, rc, (int)r);
 			GHIP(g, hipSetDevice(g->device[r]));
-			GHIP(g, hipMemcpyPeerAsync(dst0 + off, g->device[0], out, g->device[r], bytes, g->stream[r]));
-			GHIP(g, hipEventRecord(g->done[r], g->stream[r]));
+			GHIP(g, hipEventRecord(g->traced[r][c], g->stream[r]));
+			hipEvent_t arrived = g->traced[r][c];
+			if (r > 0) { // 2. the chunk to device 0 on the copy stream, beside the member's next trace
+				GHIP(g, hipStreamWaitEvent(g->copy_stream[r], g->traced[r][c], 0));
+				GHIP(g, hipMemcpyPeerAsync(dst0 + (size_t)(y0 + c0) * grid_w * wire_stride, g->device[0], block + off, g->device[r], bytes, g->copy_stream[r]));
+				GHIP(g, hipEventRecord(g->copied[r][c], g->copy_stream[r]));
+				arrived = g->copied[r][c];
+			}
+			// 3. device 0: once the chunk is there, rebuild its records on the side stream
+			GHIP(g, hipSetDevice(g->device[0]));
+			GHIP(g, hipStreamWaitEvent(g->xstream, arrived, 0));
+			if (tokens) {
+				rc = mrt_expand_grid_tokens(g->ctx[0], cam, grid_w, grid_h, y0 + c0, y0 + c1,
+						(const uint32_t *)(g->staged ? (char *)g->staged + (size_t)(y0 + c0) * grid_w * wire_stride : nullptr),
+						(mrt_hit32 *)((char *)d_out + (size_t)(y0 + c0) * grid_w * out_stride), (void *)g->xstream);
+				if (rc) return gfail_ctx(g, rc, 0);
+			}
 		}
 	}
-	// 3. device 0: wait for the peers' blocks (stream-wise), rebuild the records, hand them over
 	GHIP(g, hipSetDevice(g->device[0]));
-	for (uint32_t r = 1; r < n; r++) {
-		uint32_t y0, y1;
-		mrt_group_row_block(r, n, grid_h, &y0, &y1);
-		if (y1 > y0) GHIP(g, hipStreamWaitEvent(g->stream[0], g->done[r], 0));
-	}
-	if (tokens) {
-		rc = mrt_expand_grid_tokens(g->ctx[0], cam, grid_w, grid_h, 0, grid_h, (const uint32_t *)g->staged, (mrt_hit32 *)d_out, (void *)g->stream[0]);
-		if (rc) return gfail_ctx(g, rc, 0);
-	}
-	if (!on_device) GHIP(g, hipMemcpyAsync(hits, d_out, total * out_stride, hipMemcpyDeviceToHost, g->stream[0]));
-	GHIP(g, hipStreamSynchronize(g->stream[0]));
-	for (uint32_t r = 1; r < n; r++) { // (their buffers may be reused by the next call)
+	if (!on_device) GHIP(g, hipMemcpyAsync(hits, d_out, total * out_stride, hipMemcpyDeviceToHost, g->xstream));
+	GHIP(g, hipStreamSynchronize(g->xstream));
+	for (uint32_t r = 0; r < n; r++) { // (the members' buffers may be reused by the next call)
 		GHIP(g, hipSetDevice(g->device[r]));
 		GHIP(g, hipStreamSynchronize(g->stream[r]));
+		if (g->copy_stream[r]) GHIP(g, hipStreamSynchronize(g->copy_stream[r]));
 	}
 	return MRT_OK;
 }

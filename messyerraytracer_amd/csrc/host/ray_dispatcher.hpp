@@ -15,7 +15,9 @@
 // selects Backend::CPU (the reference's default, kept).  Nothing degrades to it silently: Backend::GPU without a
 // device, and Backend::AUTO without one, return MRT_ERR_NO_DEVICE and say so (the reference's AUTO falls back to
 // its CPU pool; this library's rule is that the device path fails loudly).  The casts therefore return an int status
-// (the reference's return void).
+// (the reference's return void).  A host that wants the reference's behaviour asks for it: set_cpu_fallback(true)
+// makes every cast that finds no usable device take the CPU pool, exactly as ray_dispatcher.h:130,152-180,214-240,
+// 247-273 do when using_gpu() is false (one line on stderr the first time it happens; used_cpu_fallback() tells).
 #pragma once
 #include <cstdint>
 #include <cstdio>
@@ -64,11 +66,19 @@ public:
 	void build() // ray_dispatcher.h:67-80
 	{
 		scene_.build();
-		if (_should_use_gpu() && gpu_caster_.is_initialized()) upload_to_gpu();
+		// A device backend with an initialised context uploads.  (The reference asks _should_use_gpu() here, which for
+		// AUTO is is_available() = "a scene is already uploaded": its AUTO never reaches the device on a first build,
+		// ray_dispatcher.h:74-79 with :433.  Here AUTO with a context uploads like GPU does.)
+		if (backend_ != Backend::CPU && gpu_caster_.is_initialized()) upload_to_gpu();
 	}
 
 	void set_backend(Backend b) { backend_ = b; }
 	Backend get_backend() const { return backend_; }
+	// Opt-in: Backend::GPU / AUTO without a usable device hand the batch to the CPU pool (the reference's routing,
+	// ray_dispatcher.h:130,152-180) instead of returning MRT_ERR_NO_DEVICE.  Off by default.
+	void set_cpu_fallback(bool on) { cpu_fallback_ = on; }
+	bool cpu_fallback() const { return cpu_fallback_; }
+	bool used_cpu_fallback() const { return fell_back_; }
 	bool gpu_available() const { return gpu_caster_.is_available(); }
 	bool gpu_initialized() const { return gpu_caster_.is_initialized(); }
 	bool initialize_gpu(int device_ordinal = 0) { return gpu_caster_.initialize(device_ordinal); }
@@ -85,10 +95,10 @@ public:
 	{
 		if (count < 0 || (count > 0 && (!rays || !results))) return MRT_ERR_INVALID;
 		if (count == 0) return MRT_OK; // a silent no-op on every backend (gpu_ray_caster.cpp:419)
-		if (backend_ == Backend::CPU) {
+		if (_route_to_cpu("cast_rays")) {
 			return _cpu_dispatch(count, stats, [&](const CpuWalker &w, int i, RayStats *s) { results[i] = w.cast(rays[i], query_mask, false, s); });
 		}
-		if (!using_gpu()) return _no_device("cast_rays");
+		if (!using_gpu()) return MRT_ERR_NO_DEVICE;
 		if (!coherent && count >= MIN_BATCH_FOR_SORTING) gpu_caster_.cast_rays_sorted(rays, results, count, query_mask);
 		else gpu_caster_.cast_rays(rays, results, count, query_mask);
 		if (stats) stats->rays_cast += (uint64_t)count;
@@ -100,10 +110,10 @@ public:
 	{
 		if (count < 0 || (count > 0 && (!rays || !hit_results))) return MRT_ERR_INVALID;
 		if (count == 0) return MRT_OK;
-		if (backend_ == Backend::CPU) {
+		if (_route_to_cpu("any_hit_rays")) {
 			return _cpu_dispatch(count, stats, [&](const CpuWalker &w, int i, RayStats *s) { hit_results[i] = w.cast(rays[i], query_mask, true, s).hit(); });
 		}
-		if (!using_gpu()) return _no_device("any_hit_rays");
+		if (!using_gpu()) return MRT_ERR_NO_DEVICE;
 		if (!coherent && count >= MIN_BATCH_FOR_SORTING) gpu_caster_.cast_rays_any_hit_sorted(rays, hit_results, count, query_mask);
 		else gpu_caster_.cast_rays_any_hit(rays, hit_results, count, query_mask);
 		if (stats) stats->rays_cast += (uint64_t)count;
@@ -113,17 +123,15 @@ public:
 	Intersection cast_ray(const Ray &ray, RayStats *stats = nullptr, uint32_t query_mask = 0xFFFFFFFF)
 	{
 		Intersection result;
-		if (backend_ == Backend::CPU) { if (scene_.built) result = _walker().cast(ray, query_mask, false, stats); }
+		if (_route_to_cpu("cast_ray")) { if (scene_.built) result = _walker().cast(ray, query_mask, false, stats); }
 		else if (using_gpu()) { gpu_caster_.cast_rays(&ray, &result, 1, query_mask); if (stats) stats->rays_cast++; }
-		else _no_device("cast_ray");
 		return result;
 	}
 	bool any_hit(const Ray &ray, RayStats *stats = nullptr, uint32_t query_mask = 0xFFFFFFFF)
 	{
 		bool result = false;
-		if (backend_ == Backend::CPU) { if (scene_.built) result = _walker().cast(ray, query_mask, true, stats).hit(); }
+		if (_route_to_cpu("any_hit")) { if (scene_.built) result = _walker().cast(ray, query_mask, true, stats).hit(); }
 		else if (using_gpu()) { gpu_caster_.cast_rays_any_hit(&ray, &result, 1, query_mask); if (stats) stats->rays_cast++; }
-		else _no_device("any_hit");
 		return result;
 	}
 
@@ -163,6 +171,8 @@ private:
 	GPURayCaster gpu_caster_;
 	ThreadPool pool_;            // persistent worker threads of the CPU backend (ray_dispatcher.h:403)
 	Backend backend_ = Backend::CPU;
+	bool cpu_fallback_ = false;  // opt-in: no usable device -> the CPU pool (the reference's routing)
+	bool fell_back_ = false;
 	static constexpr int MIN_BATCH_FOR_THREADING = 128; // ray_dispatcher.h:422
 	static constexpr int MIN_BATCH_FOR_SORTING = 256;   // ray_dispatcher.h:427
 
@@ -198,12 +208,22 @@ private:
 		}
 		return false;
 	}
-	int _no_device(const char *what) const
+	// true: this cast runs on the CPU pool.  Backend::CPU always; Backend::GPU / AUTO without a usable device only with
+	// set_cpu_fallback(true) (and says so once) -- otherwise the reason is printed and the cast returns MRT_ERR_NO_DEVICE.
+	bool _route_to_cpu(const char *what)
 	{
+		if (backend_ == Backend::CPU) return true;
+		if (using_gpu()) return false;
+		if (cpu_fallback_) {
+			if (!fell_back_) std::fprintf(stderr, "[RayDispatcher] %s: Backend::%s selected but no usable MI355X context; set_cpu_fallback(true): "
+					"routing to the CPU pool as the reference does (ray_dispatcher.h:152-180)\n", what, backend_ == Backend::AUTO ? "AUTO" : "GPU");
+			fell_back_ = true;
+			return true;
+		}
 		std::fprintf(stderr, "[RayDispatcher] %s: Backend::%s selected but no initialized MI355X context with an uploaded scene; "
-				"nothing falls back to the CPU silently (select Backend::CPU to use the CPU backend)\n", what,
+				"nothing falls back to the CPU silently (select Backend::CPU, or opt in with set_cpu_fallback(true))\n", what,
 				backend_ == Backend::AUTO ? "AUTO" : "GPU");
-		return MRT_ERR_NO_DEVICE;
+		return false;
 	}
 };
 

@@ -18,6 +18,8 @@
 // One deliberate difference: the reference's set_backend(BACKEND_GPU) prints "GPU init failed -- falling back to
 // CPU" and switches the mode; here a failed initialisation leaves the mode on GPU and every cast reports
 // MRT_ERR_NO_DEVICE (last_status()): the device path fails loudly, the CPU backend runs only when it is selected.
+// set_cpu_fallback(true) (off by default) restores the reference's behaviour: a failed initialisation prints the
+// reference's message and switches the mode to BACKEND_CPU (:346-355), and BACKEND_AUTO without a device casts on the pool.
 // Locking (shared_mutex around casts, unique around builds, :162,257,287,302) is kept.
 #pragma once
 #include <chrono>
@@ -164,7 +166,14 @@ public:
 			case BACKEND_GPU:
 				dispatcher_.set_backend(RayDispatcher::Backend::GPU);
 				if (!dispatcher_.gpu_available()) {
-					if (!dispatcher_.initialize_gpu(device_ordinal)) { last_status_ = MRT_ERR_NO_DEVICE; return; } // stays GPU: casts fail loudly
+					if (!dispatcher_.initialize_gpu(device_ordinal)) {
+						if (dispatcher_.cpu_fallback()) { // opt-in: raytracer_server.cpp:346-355
+							std::fprintf(stderr, "[RayTracerServer] GPU init failed -- falling back to CPU\n");
+							backend_mode_ = BACKEND_CPU; dispatcher_.set_backend(RayDispatcher::Backend::CPU);
+							return;
+						}
+						last_status_ = MRT_ERR_NO_DEVICE; return; // stays GPU: casts fail loudly
+					}
 					dispatcher_.upload_to_gpu();
 				}
 				break;
@@ -175,6 +184,7 @@ public:
 		}
 	}
 	int get_backend() const { return (int)backend_mode_; }
+	void set_cpu_fallback(bool on) { dispatcher_.set_cpu_fallback(on); } // opt-in, see the header comment
 	bool is_gpu_available() const { return dispatcher_.gpu_available(); }
 	int get_triangle_count() const { return dispatcher_.triangle_count(); }
 	int get_mesh_count() const { int n = 0; for (const auto &m : meshes_) n += m.valid ? 1 : 0; return n; }

@@ -11,6 +11,8 @@
 // __builtin_fmaf, so results are bit-identical to oracle/mrt_oracle.c.
 #include <hip/hip_runtime.h>
 #include <cfloat>
+#include <cstdarg>
+#include <cstdio>
 #include <cstdlib>
 #include "mrt_internal.h"
 
@@ -53,6 +55,31 @@ __device__ __forceinline__ bool lane_ray_index(const TraceParams &p, uint32_t bl
 {
 	return lane_ray_index_g(p, (uint64_t)block * MRT_WG + threadIdx.x, ray_idx, px, py);
 }
+// tile_order 3: every XCD works on its own column strips of the image.  Workgroups are dealt to the 8 XCDs round-robin
+// (workgroup i runs on XCD i & 7), and each XCD has its own 4 MB L2: in row-major launch order every XCD sees every
+// tile column, so the rows a band of tiles needs are fetched into all eight L2s (C5: 13 GB of L2 fills per launch for a
+// 1.8 GB scene).  Here the image is cut into 8 m strips (about 256 pixels wide), XCD k takes strips k, k + 8, ..., one
+// after the other, each from top to bottom: the ~1000 waves an XCD has in flight cover one compact region, and the
+// strips of every XCD are spread evenly over the image, so cheap and expensive regions balance (a contiguous band per
+// XCD, xcd_swizzle = 1, measured 6 % slower for that reason).  tile_group = consecutive tiles per workgroup.  Returns
+// false (row-major order) when the width does not split into 8 m strips of whole workgroups.
+__device__ __forceinline__ bool xcd_strips(const TraceParams &p, uint64_t tile, uint32_t tiles_x, uint32_t tiles_y, uint32_t &tx, uint32_t &ty)
+{
+	const uint32_t tg = p.tile_group ? p.tile_group : 1u;
+	uint32_t m = (tiles_x + 128u) >> 8;
+	if (m == 0u) m = 1u;
+	const uint32_t S = tiles_x / (8u * m);
+	if (S == 0u || S * 8u * m != tiles_x || S % tg != 0u) return false;
+	const uint64_t wg = tile / tg;
+	const uint32_t k = (uint32_t)wg & 7u;
+	const uint64_t j = (wg >> 3) * tg + tile % tg; // the tile's place in its XCD's own sequence
+	const uint64_t per_strip = (uint64_t)S * tiles_y;
+	const uint32_t sl = (uint32_t)(j / per_strip), r = (uint32_t)(j % per_strip);
+	ty = r / S;
+	tx = (sl * 8u + k) * S + r % S;
+	return true;
+}
+
 // g = virtual thread index: 64 consecutive g form one wave-sized group of rays
 __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t g, uint64_t &ray_idx, uint32_t &px, uint32_t &py)
 {
@@ -85,6 +112,7 @@ __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t 
 			my = (my | (my >> 1)) & 0x133u; my = (my | (my >> 2)) & 0x10Fu; my = (my | (my >> 4)) & 0x1Fu;
 			const uint32_t stx = st % (tiles_x >> 5), sty = st / (tiles_x >> 5);
 			tx = (stx << 5) + mx; ty = (sty << 5) + my;
+		} else if (p.tile_order == 3u && xcd_strips(p, tile, tiles_x, tiles_y, tx, ty)) {
 		} else { tx = (uint32_t)(tile % tiles_x); ty = (uint32_t)(tile / tiles_x); }
 		px = (tx << k) + (l & ((1u << k) - 1u));
 		py = (ty << (6u - k)) + (l >> k);
@@ -210,6 +238,10 @@ __device__ __forceinline__ void finish_two_level_ray(const TraceParams &p, uint6
 		float best_t, float best_u, float best_v, uint32_t best_slot, uint32_t best_id, uint32_t best_inst)
 {
 	int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
+	if (p.out_fmt == OUT_TOKEN8) { // {triangle slot, instance row}: expand_two_level_tokens_kernel rebuilds the record
+		reinterpret_cast<uint2 *>(p.hits)[ray_idx] = make_uint2(best_slot, best_slot != 0xFFFFFFFFu ? best_inst : 0u);
+		return;
+	}
 	if (best_slot != 0xFFFFFFFFu) {
 		prim = (int32_t)best_id;
 		if (p.out_fmt != OUT_BOOL8) {
@@ -481,6 +513,49 @@ __global__ __launch_bounds__(MRT_WG) void expand_tokens_kernel(const TraceParams
 	store_hit(p, g, r, t, (int32_t)__float_as_uint(q0.w), u, v, nn.x, nn.y, nn.z, __float_as_uint(q1.w), slot);
 }
 
+// The same for a two-level scene: a token is {triangle slot in the mesh arrays, DevInstance row}.  The ray goes to the
+// instance's mesh space with the kernels' own sequence (trace_two_level_kernel: o' = M o + t, d' = M d, every fused
+// operation an explicit fma), Moller-Trumbore runs there, and finish_two_level_ray writes the record: flat id = the
+// instance's id base + the mesh-local id, the instance's layer mask, normalize(basis * n), position on the world ray.
+__global__ __launch_bounds__(MRT_WG) void expand_two_level_tokens_kernel(const TraceParams p, const uint2 *tokens)
+{
+	const uint64_t g = (uint64_t)blockIdx.x * MRT_WG + threadIdx.x;
+	if (g >= p.count) return;
+	RayRegs r;
+	uint32_t px = 0, py = 0;
+	if (p.in_fmt == IN_GRID) { px = (uint32_t)(g % p.grid_w); py = (uint32_t)(g / p.grid_w); }
+	load_ray(p, g, px, py, r);
+	const uint2 tok = tokens[g];
+	const uint32_t slot = tok.x, inst = tok.y;
+	if (slot >= p.n_tris || inst >= p.n_instances) { // miss, or a token that is not from this scene: never read out of bounds
+		finish_two_level_ray(p, g, r, r.t_max, 0.0f, 0.0f, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u);
+		return;
+	}
+	const float4 *row = reinterpret_cast<const float4 *>(p.instances) + (size_t)inst * 8u;
+	const float4 m0 = row[0], m1 = row[1], m2 = row[2], meta = row[5];
+	const float ox = fma_(m0.x, r.ox, fma_(m0.y, r.oy, fma_(m0.z, r.oz, m0.w)));
+	const float oy = fma_(m1.x, r.ox, fma_(m1.y, r.oy, fma_(m1.z, r.oz, m1.w)));
+	const float oz = fma_(m2.x, r.ox, fma_(m2.y, r.oy, fma_(m2.z, r.oz, m2.w)));
+	const float dx = fma_(m0.x, r.dx, fma_(m0.y, r.dy, m0.z * r.dz));
+	const float dy = fma_(m1.x, r.dx, fma_(m1.y, r.dy, m1.z * r.dz));
+	const float dz = fma_(m2.x, r.dx, fma_(m2.y, r.dy, m2.z * r.dz));
+	const float4 *t3 = reinterpret_cast<const float4 *>(p.tri_hot) + (size_t)slot * 3u;
+	const float4 q0 = t3[0], q1 = t3[1], q2 = t3[2];
+	const float pvx = fma_(dy, q2.z, -(dz * q2.y));
+	const float pvy = fma_(dz, q2.x, -(dx * q2.z));
+	const float pvz = fma_(dx, q2.y, -(dy * q2.x));
+	const float det = dot3(q1.x, q1.y, q1.z, pvx, pvy, pvz);
+	const float inv_det = 1.0f / det;
+	const float tvx = ox - q0.x, tvy = oy - q0.y, tvz = oz - q0.z;
+	const float u = dot3(tvx, tvy, tvz, pvx, pvy, pvz) * inv_det;
+	const float qvx = fma_(tvy, q1.z, -(tvz * q1.y));
+	const float qvy = fma_(tvz, q1.x, -(tvx * q1.z));
+	const float qvz = fma_(tvx, q1.y, -(tvy * q1.x));
+	const float v = dot3(dx, dy, dz, qvx, qvy, qvz) * inv_det;
+	const float t = dot3(q2.x, q2.y, q2.z, qvx, qvy, qvz) * inv_det;
+	finish_two_level_ray(p, g, r, t, u, v, slot, __float_as_uint(meta.z) + __float_as_uint(q0.w), inst);
+}
+
 // ---- row-width detection for coherent batches ------------------------------------------
 // RayQuery::coherent (src/api/ray_query.h:69-76) says "these are primary camera rays" but
 // the reference's cast_rays(rays, results, count) carries no image width, and a wave of 64
@@ -658,8 +733,25 @@ hipError_t launch_origin_dir_keys(const void *rays, uint32_t in_fmt, uint64_t co
 }
 
 // ---- launch wrappers (called from api.hip) -------------------------------------------
-hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream)
+// The instantiation the last launch_trace / launch_trace_persistent of this thread put on a stream, spelled as rocprofv3
+// prints it ("trace_packet_rows_kernel<false, false, 2, 64, true>"): mrt_last_kernel_variant, which bench.py uses to
+// accept committed counter passes only for the very kernel the run used.
+static thread_local char g_variant[96] = "";
+const char *last_trace_variant() { return g_variant; }
+static void note_variant(const char *fmt, ...)
 {
+	va_list ap; va_start(ap, fmt); vsnprintf(g_variant, sizeof(g_variant), fmt, ap); va_end(ap);
+}
+#define MRT_B(x) ((x) ? "true" : "false")
+#ifndef MRT_ROWS_WG_LARGE
+#define MRT_ROWS_WG_LARGE MRT_WG // threads per workgroup of the rows kernel on large scenes
+#endif
+hipError_t launch_trace(const TraceParams &p_in, bool any_hit, bool count, hipStream_t stream)
+{
+	TraceParams p = p_in;
+	// consecutive tiles per workgroup (tile_order 3): the rows kernel's workgroup holds rows_wg / 64 waves of two tiles each
+	// (MRT_KERNEL_PACKET_DUAL) or 4 waves of one; every other kernel 4 waves of one tile
+	p.tile_group = (p.kernel == MRT_KERNEL_PACKET_DUAL && p.row_array != nullptr) ? 2u * ((p.rows_wg == 64u ? 64u : (uint32_t)MRT_ROWS_WG_LARGE) / MRT_WAVE) : MRT_WG / MRT_WAVE;
 	uint64_t threads;
 	if (p.lane_map == MAP_TILE8X8) {
 		const uint32_t th = 64u >> p.tile_w_log2;
@@ -672,12 +764,14 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 	if (p.kernel == MRT_KERNEL_TWO_LEVEL_PACKET) { // two-level scene, coherent batch: one wave per packet
 		if (any_hit) hipLaunchKernelGGL((trace_two_level_packet_kernel<true>), grid, wg, p.extra_lds, stream, p);
 		else hipLaunchKernelGGL((trace_two_level_packet_kernel<false>), grid, wg, p.extra_lds, stream, p);
+		note_variant("trace_two_level_packet_kernel<%s>", MRT_B(any_hit));
 		return hipGetLastError();
 	}
 	if (p.kernel == MRT_KERNEL_TWO_LEVEL) { // two-level scene: one lane per ray, per-lane LDS stack
 		const size_t lds2 = (size_t)(MRT_WG / MRT_WAVE) * p.stack_depth * MRT_WAVE * sizeof(uint32_t);
 		if (any_hit) hipLaunchKernelGGL((trace_two_level_kernel<true>), grid, wg, lds2, stream, p);
 		else hipLaunchKernelGGL((trace_two_level_kernel<false>), grid, wg, lds2, stream, p);
+		note_variant("trace_two_level_kernel<%s>", MRT_B(any_hit));
 		return hipGetLastError();
 	}
 	if (p.kernel == MRT_KERNEL_PACKET_QUAD && p.row_array4 != nullptr) {
@@ -689,14 +783,12 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 			else hipLaunchKernelGGL((trace_packet_quad_kernel<false, true>), rgrid, wg, p.extra_lds, stream, p);
 		} else if (any_hit) hipLaunchKernelGGL((trace_packet_quad_kernel<true, false>), rgrid, wg, p.extra_lds, stream, p);
 		else hipLaunchKernelGGL((trace_packet_quad_kernel<false, false>), rgrid, wg, p.extra_lds, stream, p);
+		note_variant("trace_packet_quad_kernel<%s, %s>", MRT_B(any_hit), MRT_B(count));
 		return hipGetLastError();
 	}
 	if ((p.kernel == MRT_KERNEL_PACKET_DUAL || p.kernel == MRT_KERNEL_PACKET_ROWS) && p.row_array != nullptr) {
 		// the walk over the unified row array: one or two packets per wave (two: half the waves)
 		const uint32_t packets = p.kernel == MRT_KERNEL_PACKET_DUAL ? 2u : 1u;
-#ifndef MRT_ROWS_WG_LARGE
-#define MRT_ROWS_WG_LARGE MRT_WG // threads per workgroup of the rows kernel on large scenes
-#endif
 		const uint32_t rows_wg = packets == 2u && p.rows_wg == 64u ? 64u : (packets == 2u ? (uint32_t)MRT_ROWS_WG_LARGE : (uint32_t)MRT_WG);
 		const uint64_t rblocks = (threads + packets * rows_wg - 1) / (packets * rows_wg);
 		dim3 rgrid((uint32_t)rblocks), rwg(rows_wg);
@@ -712,6 +804,7 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		else MRT_LAUNCH_ROWS_AC(1, MRT_WG, false);
 #undef MRT_LAUNCH_ROWS_AC
 #undef MRT_LAUNCH_ROWS
+		note_variant("trace_packet_rows_kernel<%s, %s, %u, %u, %s>", MRT_B(any_hit), MRT_B(count), packets, rows_wg, MRT_B(cull));
 		return hipGetLastError();
 	}
 	// scenes whose node offsets pass the asm loop's 32 bits use the C++ packet kernel
@@ -721,6 +814,7 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 			else hipLaunchKernelGGL((trace_packet_asm_kernel<false, true>), grid, wg, p.extra_lds, stream, p);
 		} else if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true>), grid, wg, p.extra_lds, stream, p);
 		else hipLaunchKernelGGL((trace_packet_asm_kernel<false>), grid, wg, p.extra_lds, stream, p);
+		note_variant("trace_packet_asm_kernel<%s, %s>", MRT_B(any_hit), MRT_B(count));
 		return hipGetLastError();
 	}
 	if (p.kernel == MRT_KERNEL_PACKET || p.kernel == MRT_KERNEL_PACKET_ASM || p.kernel == MRT_KERNEL_PACKET_DUAL || p.kernel == MRT_KERNEL_PACKET_ROWS || p.kernel == MRT_KERNEL_PACKET_QUAD) {
@@ -731,6 +825,7 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 			if (count) hipLaunchKernelGGL((trace_packet_kernel<false, true>), grid, wg, 0, stream, p);
 			else hipLaunchKernelGGL((trace_packet_kernel<false, false>), grid, wg, 0, stream, p);
 		}
+		note_variant("trace_packet_kernel<%s, %s>", MRT_B(any_hit), MRT_B(count));
 		return hipGetLastError();
 	}
 	const size_t lds = (size_t)(MRT_WG / MRT_WAVE) * p.stack_depth * MRT_WAVE * sizeof(uint32_t);
@@ -741,6 +836,7 @@ hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStrea
 		if (count) hipLaunchKernelGGL((trace_lane_kernel<false, true>), grid, wg, lds, stream, p);
 		else hipLaunchKernelGGL((trace_lane_kernel<false, false>), grid, wg, lds, stream, p);
 	}
+	note_variant("trace_lane_kernel<%s, %s>", MRT_B(any_hit), MRT_B(count));
 	return hipGetLastError();
 }
 
@@ -780,6 +876,11 @@ hipError_t launch_trace_persistent(const TraceParams &p, unsigned long long *nex
 		if (any_hit) hipLaunchKernelGGL((trace_lane_persistent_kernel<true, 2>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
 		else hipLaunchKernelGGL((trace_lane_persistent_kernel<false, 2>), dim3(blocks), dim3(MRT_WG), lds, stream, p, q);
 	}
+	{
+		const bool tl = p.kernel == MRT_KERNEL_TWO_LEVEL_PERSISTENT || p.kernel == MRT_KERNEL_TWO_LEVEL_PERSISTENT8;
+		const int width = tl ? ((p.kernel == MRT_KERNEL_TWO_LEVEL_PERSISTENT8 && p.nodes8 != nullptr && p.leaf_box != nullptr) ? 8 : 2) : (wide8 ? 8 : (wide4 ? 4 : 2));
+		note_variant("trace_lane_persistent_kernel<%s, %d, %s, %s>", MRT_B(any_hit), width, MRT_B(tl), MRT_B(count && !tl));
+	}
 	return hipGetLastError();
 }
 
@@ -795,7 +896,9 @@ hipError_t launch_expand_tokens(const TraceParams &p, const uint32_t *tokens, hi
 {
 	if (p.count == 0) return hipSuccess;
 	const uint64_t blocks = (p.count + MRT_WG - 1) / MRT_WG;
-	hipLaunchKernelGGL(expand_tokens_kernel, dim3((uint32_t)blocks), dim3(MRT_WG), 0, stream, p, tokens);
+	if (p.instances != nullptr) // a two-level scene: 8-byte tokens {triangle slot, instance row}
+		hipLaunchKernelGGL(expand_two_level_tokens_kernel, dim3((uint32_t)blocks), dim3(MRT_WG), 0, stream, p, reinterpret_cast<const uint2 *>(tokens));
+	else hipLaunchKernelGGL(expand_tokens_kernel, dim3((uint32_t)blocks), dim3(MRT_WG), 0, stream, p, tokens);
 	return hipGetLastError();
 }
 

@@ -96,7 +96,9 @@ constexpr uint32_t kLastInLeaf = 1u;
 enum InFmt : uint32_t { IN_RAY32 = 0, IN_HOST60 = 1, IN_GRID = 2 };
 // OUT_TOKEN4: one u32 per ray = leaf-order slot of the winning triangle (0xFFFFFFFF = miss); the
 // full record is rebuilt from (ray, slot) by expand_tokens_kernel, bit for bit
-enum OutFmt : uint32_t { OUT_HIT32 = 0, OUT_HOST44 = 1, OUT_BOOL8 = 2, OUT_TOKEN4 = 3 };
+// OUT_TOKEN8 (two-level scenes): two u32 per ray = {slot of the winning triangle in its mesh's arrays (0xFFFFFFFF =
+// miss), DevInstance row of the instance it was hit in}: the record is a function of (ray, triangle, instance)
+enum OutFmt : uint32_t { OUT_HIT32 = 0, OUT_HOST44 = 1, OUT_BOOL8 = 2, OUT_TOKEN4 = 3, OUT_TOKEN8 = 4 };
 enum LaneMap : uint32_t { MAP_LINEAR = 0, MAP_TILE8X8 = 1, MAP_AUTO = 2 };
 
 struct DevInstance;
@@ -127,11 +129,13 @@ struct TraceParams {
 	uint32_t grid_w, grid_h, y0, rows; // IN_GRID / MAP_TILE8X8: rows [y0, y0+rows) of a grid_w x grid_h grid
 	uint32_t tiles_x;          // ceil(grid_w / tile width)
 	uint32_t tile_w_log2;      // lane tile: 2^k wide, 64 / 2^k high
-	uint32_t tile_order;       // 0: tiles row-major, 1: Z-order inside 16x16-tile super-tiles
+	uint32_t tile_order;       // 0: tiles row-major, 1: Z-order inside 16x16-tile super-tiles, 2: 32x32, 3: column strips per XCD
+	uint32_t tile_group;       // tile_order 3: consecutive tiles per workgroup (set by launch_trace)
 	uint32_t kernel;           // MRT_KERNEL_LANE / MRT_KERNEL_PACKET
 	uint32_t stack_depth;      // LDS stack entries per lane
 	uint32_t xcd_swizzle;      // 1: remap blockIdx so each XCD owns a contiguous band
 	uint32_t n_tris;           // rows in tri_hot / tri_cold (token validation)
+	uint32_t n_instances;      // rows in instances (two-level scenes; token validation)
 	uint32_t n_nodes;          // rows in nodes (the hand-written node loop addresses them with a 32-bit byte offset)
 	uint32_t count_mode;       // COUNT variants: mrt_options.count_visits (1: visit counters, 2: only the sampled clock of the rows kernel)
 	uint32_t extra_lds;        // experiments: dynamic LDS bytes added per workgroup of the packet kernels (occupancy sweeps)

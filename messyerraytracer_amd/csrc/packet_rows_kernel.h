@@ -546,6 +546,19 @@ struct PacketRegs {
 	"v_lshl_add_u32 v62, " REF ", 6, %[cvo]\n"                                                                      \
 	"global_load_dword " VDST ", v62, %[rows]\n"
 
+// (optional, -DMRT_ROWSC_KPF=1: also the scalar-cache prefetch of MRT_ROWS_LOOPW; the vector copies already pull both rows to the L2)
+#ifndef MRT_ROWSC_KPF
+#define MRT_ROWSC_KPF 0
+#endif
+#if MRT_ROWSC_KPF
+#define MRT_ROWSC_KPREFETCH                                                                                           \
+	"s_lshl_b32 s46, " RA_LREF ", 6\n"                                                                               \
+	"s_lshl_b32 s47, " RA_RREF ", 6\n"                                                                               \
+	"s_load_dword s64, %[rows], s46\n"                                                                              \
+	"s_load_dword s65, %[rows], s47\n"
+#else
+#define MRT_ROWSC_KPREFETCH ""
+#endif
 // In: cur (group A's operand) = a row to visit, the groups' own masks, the lane's cull constants.  Out: cur = 0x7FFFFFFF.
 // Stack entries as in MRT_ROWS_LOOPW.
 #define MRT_ROWS_LOOPC(CNT_N, CNT_T, CNT_P, ANYA, ANYB, ANYDONE, BX, BY, BZ)                                          \
@@ -572,6 +585,7 @@ struct PacketRegs {
 		"s_nop 1\n"                                                                                                 \
 		"v_add_f32_dpp v59, v58, v58 row_shr:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"                           \
 		"v_cmp_lt_f32_e64 s[44:45], v59, %[ccc]\n" /* bit 16 r + 7: the left box is outside plane r; 16 r + 15: the right one */ \
+		MRT_ROWSC_KPREFETCH                                                                                         \
 		"s_or_b32 s44, s44, s45\n"                                                                                  \
 		MRT_ROWSC_CHILD(L, "v50", "0x00800080", "s[36:37]", "s[40:41]", BX, BY, BZ)                                 \
 		MRT_ROWSC_CHILD(R, "v56", "0x80008000", "s[38:39]", "s[42:43]", BX, BY, BZ)                                 \
@@ -838,6 +852,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS_WPE
 		if (block < (per << 3)) block = (block & 7u) * per + (block >> 3);
 	}
 	const uint32_t wave = threadIdx.x / MRT_WAVE, lane = threadIdx.x & (MRT_WAVE - 1);
+	const uint32_t wave_s = __builtin_amdgcn_readfirstlane(wave), block_s = block; // (scalars: for the epilogue)
 	const uint64_t g_a = (((uint64_t)block * (WG / MRT_WAVE) + wave) * PACKETS) * MRT_WAVE + lane, g_b = g_a + MRT_WAVE;
 	uint64_t idx = 0; uint32_t px = 0, py = 0;
 	const bool valid_a = lane_ray_index_g(p, g_a, idx, px, py);
@@ -907,9 +922,15 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS_WPE
 		if (COUNT) { cnt_n += __builtin_amdgcn_readfirstlane(nn); cnt_t += __builtin_amdgcn_readfirstlane(nt); }
 	}
 
-	// the rays' indices again (not kept across the walk: registers)
-	if (valid_a) { lane_ray_index_g(p, g_a, idx, px, py); finish_ray(p, idx, ra, A.bt, A.bu, A.bv, slot_a); }
-	if (PACKETS == 2 && valid_b) { lane_ray_index_g(p, g_b, idx, px, py); finish_ray(p, idx, rb, B.bt, B.bu, B.bv, slot_b); }
+	// The rays' indices again, from nothing the prologue computed (the wave from a scalar, the lane from the thread id):
+	// no index, pixel or validity flag stays live across the walk, where every vector register is spoken for.
+	{
+		const uint32_t lane2 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+		const uint64_t h_a = (((uint64_t)block_s * (WG / MRT_WAVE) + wave_s) * PACKETS) * MRT_WAVE + lane2;
+		uint64_t idx2 = 0; uint32_t px2 = 0, py2 = 0;
+		if (lane_ray_index_g(p, h_a, idx2, px2, py2)) finish_ray(p, idx2, ra, A.bt, A.bu, A.bv, slot_a);
+		if (PACKETS == 2 && lane_ray_index_g(p, h_a + MRT_WAVE, idx2, px2, py2)) finish_ray(p, idx2, rb, B.bt, B.bu, B.bv, slot_b);
+	}
 
 	if (COUNT && lane == 0u && (p.count_mode != 2u || (blockIdx.x & 15u) == 0u)) { // the wave's clock: cycles in the row-fetch waits of the one-packet loop, cycles in all
 		atomicAdd(&p.counters[kCntFetchWaitCycles], (unsigned long long)cnt_w);

@@ -25,7 +25,7 @@ import torch
 import torch.distributed as dist
 
 HIT_BYTES = 32    # mrt_hit32 / GPUIntersectionPacked (src/api/gpu_types.h:87-92)
-TOKEN_BYTES = 4   # MRT_FLAG_TOKEN_OUT
+TOKEN_BYTES = 4   # MRT_FLAG_TOKEN_OUT on a flat scene; a two-level scene writes 8 ({triangle, instance}): pass token_bytes = ctx.token_bytes()
 
 
 def row_block(rank: int, world: int, rows: int) -> Tuple[int, int]:
@@ -99,8 +99,8 @@ class ShardedGrid:
     """Rows [0, rows) of a `width`-wide hit image, sharded over the ranks of `group`.
 
     tracer(y0, y1, out) must fill `out` (a uint8 tensor view on this rank's device) with
-    the results of rows [y0, y1): 32-byte hit records, or 4-byte tokens when an
-    `expander` is given.  expander(y0, y1, tokens, hits, stream) (rank 0 only) rebuilds the
+    the results of rows [y0, y1): 32-byte hit records, or hit tokens (token_bytes each: 4, or 8 for a
+    two-level scene) when an `expander` is given.  expander(y0, y1, tokens, hits, stream) (rank 0 only) rebuilds the
     records of rows [y0, y1) on `stream`.  On the GPU these wrap mrt_cast_grid /
     mrt_expand_grid_tokens on the rank's context; the CPU tests inject pattern generators
     to exercise the exchange path under gloo.
@@ -108,7 +108,7 @@ class ShardedGrid:
 
     def __init__(self, width: int, rows: int, tracer: Callable[[int, int, torch.Tensor], None],
                  device: torch.device, chunks: int = 4, group=None, gather: bool = True,
-                 expander: Optional[Callable] = None):
+                 expander: Optional[Callable] = None, token_bytes: int = TOKEN_BYTES):
         self.width, self.rows, self.tracer, self.device = width, rows, tracer, device
         self.group = group
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -120,7 +120,7 @@ class ShardedGrid:
         self.token_mode = self.expander is not None  # what the tracer must write: tokens or records
         # bytes per row of what is traced / exchanged, and of the assembled image
         self.row_bytes = width * HIT_BYTES
-        self.xrow_bytes = width * (TOKEN_BYTES if self.expander else HIT_BYTES)
+        self.xrow_bytes = width * (token_bytes if self.expander else HIT_BYTES)
         self.local = torch.empty((self.y1 - self.y0) * self.xrow_bytes, dtype=torch.uint8, device=device)
         # rank 0 holds the whole image; every rank's block has its own slot
         self.image: Optional[torch.Tensor] = None
@@ -206,7 +206,7 @@ class ShardedViews:
 
     def __init__(self, width: int, rows: int, tracer: Callable[[int, int, torch.Tensor], None],
                  device: torch.device, chunks: int = 4, group=None, gather: bool = True, force_gather: bool = False,
-                 expander: Optional[Callable] = None, depth: int = 1):
+                 expander: Optional[Callable] = None, depth: int = 1, token_bytes: int = TOKEN_BYTES):
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.width, self.rows, self.tracer, self.group = width, rows, tracer, group
@@ -217,7 +217,7 @@ class ShardedViews:
         self.token_mode = self.expander is not None  # what the tracer must write: tokens or records
         self.depth = max(1, min(int(depth), 2)) if self.gather else 1
         self.row_bytes = width * HIT_BYTES
-        self.xrow_bytes = width * (TOKEN_BYTES if self.expander else HIT_BYTES)
+        self.xrow_bytes = width * (token_bytes if self.expander else HIT_BYTES)
         # what this rank traces into / sends from, one buffer per frame in flight
         self.local = torch.empty((self.depth, rows * self.xrow_bytes), dtype=torch.uint8, device=device)
         self.images = None   # rank 0: [frame slot][view] records (token mode: one slot, written in frame order)
@@ -310,7 +310,7 @@ class BalancedViews:
     expander(view, y0, y1, tokens, hits, stream): rank 0, records of those rows on `stream`."""
 
     def __init__(self, width: int, rows: int, tracer: Callable, expander: Callable, device: torch.device,
-                 root_share: float = 1.0, group=None, depth: int = 2):
+                 root_share: float = 1.0, group=None, depth: int = 2, token_bytes: int = TOKEN_BYTES):
         if not dist.is_initialized():
             raise RuntimeError("BalancedViews needs an initialised process group (use ShardedViews without one)")
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
@@ -319,7 +319,7 @@ class BalancedViews:
         self.depth = max(1, min(int(depth), 2))
         self.spans = balanced_spans(self.world, rows, root_share)
         self.pay_rows = max(sum(y1 - y0 for (_, y0, y1) in s) for s in self.spans)
-        self.row_bytes, self.xrow_bytes = width * HIT_BYTES, width * TOKEN_BYTES
+        self.row_bytes, self.xrow_bytes = width * HIT_BYTES, width * token_bytes
         self.local = torch.zeros((self.depth, self.pay_rows * self.xrow_bytes), dtype=torch.uint8, device=device)
         self.images = self.staged = self.side = None
         if self.rank == 0:

@@ -19,8 +19,13 @@
 
 #include <atomic>
 #include <cfloat>
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -40,26 +45,76 @@ struct RefScene {
 	bool use_avx2 = false, has4 = false, has8 = false;
 };
 
-// ThreadPool::dispatch_and_wait, src/dispatch/thread_pool.h:77-133,173-222:
-// chunks = workers + 1, chunk = ceil(count / chunks), caller runs chunk 0,
-// workers grab the remaining chunks through one atomic counter.
+// The reference's pool contract (src/dispatch/thread_pool.h:41-55,77-133): PERSISTENT helper threads (created once,
+// parked on a condition variable between dispatches), chunks = helpers + 1, chunk = ceil(count / chunks), the caller
+// runs chunk 0, the helpers claim the remaining chunks through one atomic counter, the dispatch returns when every
+// chunk has run.  One pool per thread count, kept for the life of the library (the timed baseline pays no thread
+// start; round 2's harness started fresh std::threads per call).
+class Pool {
+public:
+	explicit Pool(int helpers) : n_(helpers) { for (int i = 0; i < n_; i++) th_.emplace_back([this] { loop(); }); }
+	~Pool() { { std::lock_guard<std::mutex> g(m_); quit_ = true; } wake_.notify_all(); for (auto &t : th_) t.join(); }
+	int helpers() const { return n_; }
+	template <class F> void run(int64_t count, int64_t chunk, F &fn)
+	{
+		const int64_t chunks = (count + chunk - 1) / chunk;
+		{
+			std::lock_guard<std::mutex> g(m_);
+			call_ = [&fn](int64_t a, int64_t b) { fn(a, b); };
+			count_ = count; chunk_ = chunk; left_.store(chunks); next_.store((uint64_t)(++epoch_) << 32 | 1u);
+		}
+		wake_.notify_all();
+		one(0);
+		std::unique_lock<std::mutex> g(m_);
+		done_.wait(g, [this] { return left_.load() == 0; });
+	}
+private:
+	int n_; std::vector<std::thread> th_;
+	std::mutex m_; std::condition_variable wake_, done_;
+	bool quit_ = false; uint32_t epoch_ = 0;
+	std::function<void(int64_t, int64_t)> call_;
+	int64_t count_ = 0, chunk_ = 1;
+	std::atomic<uint64_t> next_{0}; std::atomic<int64_t> left_{0};
+	void one(int64_t c)
+	{
+		const int64_t s = c * chunk_;
+		call_(s, std::min(s + chunk_, count_));
+		if (left_.fetch_sub(1) == 1) { std::lock_guard<std::mutex> g(m_); done_.notify_all(); }
+	}
+	void loop()
+	{
+		uint32_t seen = 0;
+		for (;;) {
+			uint32_t e; int64_t chunks;
+			{
+				std::unique_lock<std::mutex> g(m_);
+				wake_.wait(g, [&] { return quit_ || epoch_ != seen; });
+				if (quit_) return;
+				seen = e = epoch_; chunks = (count_ + chunk_ - 1) / chunk_;
+			}
+			uint64_t t = next_.load();
+			while ((uint32_t)(t >> 32) == e && (int64_t)(uint32_t)t < chunks)
+				if (next_.compare_exchange_weak(t, t + 1)) { one((int64_t)(uint32_t)t); t = next_.load(); }
+		}
+	}
+};
+
 template <class F> void range_split(int64_t count, int n_threads, int min_batch, F fn)
 {
 	if (count <= 0) return;
-	int workers = n_threads - 1;
-	if (count <= min_batch || workers <= 0) { fn(0, count); return; }
-	int64_t chunks = workers + 1, chunk = (count + chunks - 1) / chunks;
-	std::atomic<int64_t> next{1};
-	std::vector<std::thread> pool;
-	for (int w = 0; w < workers; w++) pool.emplace_back([&] {
-		for (;;) {
-			int64_t c = next.fetch_add(1), s = c * chunk;
-			if (s >= count) break;
-			fn(s, std::min(s + chunk, count));
-		}
-	});
-	fn(0, std::min(chunk, count));
-	for (auto &t : pool) t.join();
+	const int helpers = n_threads - 1;
+	if (count <= min_batch || helpers <= 0) { fn(0, count); return; }
+	static std::mutex pools_m;
+	static std::map<int, std::unique_ptr<Pool>> pools;
+	Pool *pool;
+	{
+		std::lock_guard<std::mutex> g(pools_m);
+		auto &slot = pools[helpers];
+		if (!slot) slot.reset(new Pool(helpers));
+		pool = slot.get();
+	}
+	const int64_t chunks = helpers + 1, chunk = (count + chunks - 1) / chunks;
+	pool->run(count, chunk, fn);
 }
 
 } // namespace

@@ -33,9 +33,15 @@ def test_bench_prints_one_json_line_with_the_contract_keys(built):
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9
     assert 0.0 < roof["frac"] <= 1.0, "a roofline fraction is a fraction"
-    assert roof["kernel"].startswith("trace_packet") and roof["algorithmic"]["node_rows"] > 0
+    assert roof["kernel"].startswith("trace_packet_rows_kernel<false, false, 2, ") and roof["algorithmic"]["node_rows"] > 0   # the instantiation, as rocprofv3 spells it
+    assert roof["kernel_ms"] > 0 and "median" in roof["kernel_ms_is"] and roof["kernel_ms_mean"] > 0
+    # committed counter passes are reported only for this very kernel on this very source tree; otherwise the line says why not
+    assert (roof["traffic"] is not None) != ("traffic_rejected" in roof) or roof["traffic"] is None
+    if roof["traffic"] is not None:
+        assert roof["traffic_source"].count(j["source_sha16"]) == 1
     # the timed launches did the work: the last frame's digest equals the oracle's digest of the whole grid
     assert j["verified"]["hit_count"] == 16649551 and j["verified"]["rays"] == 16777216
     assert j["end_to_end_host_mrays"] > 100.0
     cpu = j["cpu_baseline"]
     assert cpu["kind"] in ("reference", "port") and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "Mrays/s"
+    assert cpu["cores"] <= cpu["cpus_allowed"] and cpu["cpu_model"] and "median of 5" in cpu["sample"]   # one socket's cores, stated

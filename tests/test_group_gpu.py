@@ -50,7 +50,9 @@ def test_group_two_level_scene(ctx):
     want = ctx.cast_grid(cam, w, h)
     g = capi.Group([0, 0, 0])
     g.upload_two_level_scene(local, inst)
-    assert g.cast_grid(cam, w, h).tobytes() == want.tobytes()   # (records travel: tokens need a flat scene)
+    assert g.cast_grid(cam, w, h).tobytes() == want.tobytes()   # 8-byte tokens {triangle, instance} travel, records rebuilt on member 0
+    b = g.cast_grid(cam, w, h, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT)
+    assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
     g.close()
 
 

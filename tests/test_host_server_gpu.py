@@ -1,0 +1,37 @@
+"""RayTracerServer semantics on the DEVICE backend (src/godot/raytracer_server.cpp:253-366): the C++
+mirror (csrc/host/ray_tracer_server.hpp) with set_backend(BACKEND_GPU) / BACKEND_AUTO, every call through the C-ABI:
+cast_ray (direction normalised, default mask 0x7FFFFFFF), any_hit (t_max = max_distance), cast_rays_batch, submit nearest /
+any-hit / with the coherent hint (elapsed_ms > 0, RayStats.rays_cast), against the oracle bit for bit."""
+import numpy as np
+import pytest
+
+from messyerraytracer_amd import synth
+from oracle import pyoracle as po
+import server_driver as sd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", ["gpu", "auto"])
+def test_server_on_the_device_backend(built, mode):
+    local, inst = synth.multi_mesh_instances(3, 1500, 0.3, 77)
+    meshes = []
+    for i in range(3):
+        a, b = int(inst[i]["first_tri"]), int(inst[i]["first_tri"] + inst[i]["n_tris"])
+        meshes.append((local[a:b], inst[i]["basis"], inst[i]["origin"], [0x1, 0x6, 0x80000001][i]))
+    rays = np.concatenate([po.grid_rays((0, 0, -12), (0, 0, 1), 64, 48, 50.0), synth.incoherent_rays(3000, 5)])
+    sd.check(meshes, rays, 0xFFFFFFFF, mode=mode)    # >= 256 rays without the hint: Morton-sorted on the device
+    sd.check(meshes, rays, 0x4, mode=mode)           # only the second mesh is visible: the mask filters during traversal
+    sd.check(meshes[:1], rays[:100], 0x1, mode=mode)  # below MIN_BATCH_FOR_SORTING
+
+
+def test_c1_cube_through_the_server_on_the_device(built):
+    c1 = synth.CONFIGS["C1"]
+    rays = po.grid_rays(c1["origin"], c1["forward"], *c1["grid"], c1["fov"])
+    sd.check([(synth.cube(), np.eye(3).reshape(9), (0, 0, 0), 0xFFFFFFFF)], rays, 0xFFFFFFFF, mode="gpu")
+
+
+def test_fallback_modes_use_the_device_when_there_is_one(built):
+    v = synth.soup(800, 0.4, 31)
+    rays = np.concatenate([po.grid_rays((0, 0, -12), (0, 0, 1), 24, 16, 50.0), synth.incoherent_rays(300, 3)])
+    sd.check([(v, np.eye(3).reshape(9), (0, 0, 0), 0xFFFFFFFF)], rays, 0xFFFFFFFF, mode="auto-fallback")

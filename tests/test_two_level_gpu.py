@@ -281,3 +281,65 @@ def test_c5_two_level_kernel_forms_agree_at_full_size(built):
     a, b = out[capi.KERNEL_AUTO], out[capi.KERNEL_LANE]
     assert a[0] == b[0], "packet form != lane form on the 8192^2 grid"
     assert a[1] == b[1] and a[2] == b[2] and a[1] == a[2], "persistent form != lane form on incoherent rays"
+
+
+@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE])
+def test_two_level_hit_tokens_expand_to_identical_records(built, kernel):
+    """MRT_FLAG_TOKEN_OUT on a two-level scene: 8 bytes per ray, {triangle slot in its mesh, instance} (mrt_token_bytes), and
+    mrt_expand_tokens / mrt_expand_grid_tokens rebuild the records of a plain cast byte for byte -- on this context and on
+    another one that uploaded the same scene by itself (another rank): what lets the multi-GPU gather of BASELINE config 5
+    ("TLAS/BLAS multi-mesh scene ... RCCL gather") move 8 bytes per ray instead of 32.  Every kernel form of the two-level
+    walk: the packet form (grids, coherent batches), one lane per ray, resident waves (the large batch)."""
+    local, inst = _scene()
+    c, other = capi.Context(0, kernel=kernel), capi.Context(0)
+    c.upload_two_level_scene(local, inst)
+    other.upload_two_level_scene(local, inst)
+    assert c.token_bytes() == 8
+    osc = po.OracleTwoLevelScene(local, inst)
+    grid, inc = _rays()
+    big = np.concatenate([inc, grid, inc[::-1], grid[::-1], inc])    # large enough for the persistent form
+    for rays, name in ((grid, "grid"), (inc, "incoherent"), (big, "big")):
+        n = rays.shape[0]
+        d_rays, d_tok, d_hits = c.device_alloc(rays.nbytes), c.device_alloc(n * 8), c.device_alloc(n * 32)
+        o_rays, o_tok, o_hits = other.device_alloc(rays.nbytes), other.device_alloc(n * 8), other.device_alloc(n * 32)
+        c.h2d(d_rays, rays); other.h2d(o_rays, rays)
+        for mask in (0xFFFFFFFF, 0x2):
+            want = osc.trace(rays, query_mask=mask)
+            for flags in (capi.FLAG_COHERENT, 0):
+                tok = c.cast(rays, query_mask=mask, flags=flags | capi.FLAG_TOKEN_OUT)
+                assert tok.shape == (n, 2) and tok.dtype == np.uint32
+                assert np.array_equal(tok[:, 0] != capi.TOKEN_MISS, want["prim_id"] >= 0)
+                c.h2d(d_tok, tok)
+                c.expand_tokens(d_rays, d_tok, d_hits, n)
+                c.synchronize()
+                got = np.zeros(n, dtype=T.HIT32)
+                c.d2h(got, d_hits)
+                parity.assert_exact(got, want, f"two-level tokens {name} mask={mask:#x} flags={flags}")
+                other.h2d(o_tok, tok)
+                other.expand_tokens(o_rays, o_tok, o_hits, n)
+                other.synchronize()
+                other.d2h(got, o_hits)
+                assert got.tobytes() == want.tobytes(), "tokens mean the same on another context with the same scene"
+        for p in (d_rays, d_tok, d_hits):
+            c.device_free(p)
+        for p in (o_rays, o_tok, o_hits):
+            other.device_free(p)
+    # the grid form: tokens of rows [y0, y1) written by mrt_cast_grid, records rebuilt from the camera
+    w, h = 160, 120
+    cam = capi.camera_look((0, 0, -12), (0, 0, 1), w, h, 50.0)
+    want = osc.trace(grid)
+    d_tok, d_hits = c.device_alloc(w * h * 8), other.device_alloc(w * h * 32)
+    for (y0, y1) in ((0, h), (17, 93)):
+        c.cast_grid(cam, w, h, y0=y0, y1=y1, hits=d_tok, flags=capi.FLAG_HITS_ON_DEVICE | capi.FLAG_TOKEN_OUT)
+        tok = np.zeros(((y1 - y0) * w, 2), dtype=np.uint32)
+        c.d2h(tok, d_tok)
+        o_tok = other.device_alloc(tok.nbytes)
+        other.h2d(o_tok, tok)
+        other.expand_grid_tokens(cam, w, h, y0, y1, o_tok, d_hits)
+        other.synchronize()
+        got = np.zeros((y1 - y0) * w, dtype=T.HIT32)
+        other.d2h(got, d_hits)
+        other.device_free(o_tok)
+        assert got.tobytes() == want[y0 * w:y1 * w].tobytes()
+    c.device_free(d_tok); other.device_free(d_hits)
+    c.close(); other.close()

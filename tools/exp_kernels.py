@@ -48,6 +48,8 @@ VARIANTS = {
     "rows1_fused": (dict(kernel=capi.KERNEL_PACKET_ROWS), "fused"),
     "rows1_cast": (dict(kernel=capi.KERNEL_PACKET_ROWS), "cast"),
     "dual_fused": (dict(kernel=capi.KERNEL_PACKET_DUAL), "fused"),
+    "dual_nocull_fused": (dict(kernel=capi.KERNEL_PACKET_DUAL, packet_cull=1), "fused"),
+    "dual_nocull_cast": (dict(kernel=capi.KERNEL_PACKET_DUAL, packet_cull=1), "cast"),
     "dual_cast": (dict(kernel=capi.KERNEL_PACKET_DUAL), "cast"),
     "dual_fused_zorder": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=2), "fused"),
     "dual_fused_rowmajor": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=1), "fused"),
@@ -55,12 +57,22 @@ VARIANTS = {
     "dual_fused_zorder32": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=3), "fused"),
     "dual_cull_fused": (dict(kernel=capi.KERNEL_PACKET_DUAL, packet_cull=2), "fused"),
     "dual_cull_cast": (dict(kernel=capi.KERNEL_PACKET_DUAL, packet_cull=2), "cast"),
+    "dual_fused_strips": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=4), "fused"),
+    "dual_cast_strips": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=4), "cast"),
+    "dual_cull_strips": (dict(kernel=capi.KERNEL_PACKET_DUAL, tile_order=4, packet_cull=2), "fused"),
+    "dual_fused_wg256": (dict(kernel=capi.KERNEL_PACKET_DUAL, packet_wg=256), "fused"),
+    "dual_fused_wg256_strips": (dict(kernel=capi.KERNEL_PACKET_DUAL, packet_wg=256, tile_order=4), "fused"),
+    "dual_fused_wg64": (dict(kernel=capi.KERNEL_PACKET_DUAL, packet_wg=64), "fused"),
+    "dual_fused_wg64_strips": (dict(kernel=capi.KERNEL_PACKET_DUAL, packet_wg=64, tile_order=4), "fused"),
+    "dual_fused_wg64_rowmajor": (dict(kernel=capi.KERNEL_PACKET_DUAL, packet_wg=64, tile_order=1), "fused"),
+    "asm_fused_strips": (dict(kernel=capi.KERNEL_PACKET_ASM, tile_order=4), "fused"),
     "quad_fused": (dict(kernel=capi.KERNEL_PACKET_QUAD), "fused"),
     "quad_cast": (dict(kernel=capi.KERNEL_PACKET_QUAD), "cast"),
     "auto_cast": (dict(), "cast"),
     "auto_tiled": (dict(), "tiled"),
     "persist2_linear": (dict(kernel=capi.KERNEL_LANE_PERSISTENT), "cast"),
     "persist4_linear": (dict(kernel=capi.KERNEL_LANE4_PERSISTENT), "cast"),
+    "persist8_linear": (dict(kernel=capi.KERNEL_LANE8_PERSISTENT), "cast"),
     "persist4_linear_l32": (dict(kernel=capi.KERNEL_LANE4_PERSISTENT, leaf_wait=32), "cast"),
     "persist4_linear_l8": (dict(kernel=capi.KERNEL_LANE4_PERSISTENT, leaf_wait=8), "cast"),
 }

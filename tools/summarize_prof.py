@@ -89,6 +89,15 @@ def main():
         b = summary.get("bench_line_under_rocprof", {})
         if b.get("roofline", {}).get("rays_per_step_rank0"):
             rec["rays_per_launch"] = b["roofline"]["rays_per_step_rank0"]
+        # what bench.py checks before it reports these figures: the tree the passes ran on and the commit they belong to
+        rec["source_sha16"] = b.get("source_sha16")
+        try:
+            import subprocess
+            head = subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+            dirty = subprocess.run(["git", "status", "--porcelain", "--", "messyerraytracer_amd/csrc"], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+            rec["commit"] = head + ("+uncommitted kernel sources" if dirty else "")
+        except OSError:
+            rec["commit"] = None
         if "SQ_INSTS_VALU" in pmc:
             rec["valu_insts_per_launch"] = pmc["SQ_INSTS_VALU"]
         if "effective_clock_ghz" in summary:
