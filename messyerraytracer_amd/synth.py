@@ -115,6 +115,34 @@ def incoherent_rays(m: int, seed: int = 7, extent: float = 6.0) -> np.ndarray:
     return rays
 
 
+def incoherent_rays_at(index: np.ndarray, seed: int = 7, extent: float = 6.0) -> np.ndarray:
+    """Rays index[0], index[1], ... of incoherent_rays(m, seed, extent) for any m > max(index), without generating the
+    whole batch (the generator is counter based: ray i takes draws [3 i, 3 i + 3) of the origin stream and draws
+    [24 i, 24 i + 24) of each rejection round of the direction stream).  Same arithmetic, same bits."""
+    index = np.asarray(index, dtype=np.int64)
+    rays = np.zeros(index.shape[0], dtype=RAY32)
+    d = np.zeros((index.shape[0], 3), dtype=np.float32)
+    for j, i in enumerate(index):
+        i = int(i)
+        u = uniform01(seed, i * 3, 3)
+        rays["origin"][j] = u * np.float32(2.0 * extent) - np.float32(extent)
+        rnd = 0
+        while True:   # _unit_vectors(seed + 0x0DD5EED, m, 3), element i: first of 8 candidates per round inside the unit ball
+            c = uniform01(seed + 0x0DD5EED + rnd * 7919, i * 24, 24).reshape(8, 3) * np.float32(2.0) - np.float32(1.0)
+            l2 = (c * c).sum(axis=1, dtype=np.float32)
+            ok = (l2 <= np.float32(1.0)) & (l2 >= np.float32(1e-4))
+            if ok.any():
+                k = int(ok.argmax())
+                d[j] = (c[k] / np.sqrt(l2[k])).astype(np.float32)
+                break
+            rnd += 1
+    l = np.sqrt((d * d).sum(axis=1, dtype=np.float32))
+    rays["direction"] = (d / l[:, None]).astype(np.float32)
+    rays["t_min"] = np.float32(0.001)
+    rays["t_max"] = FLT_MAX
+    return rays
+
+
 def multi_mesh(n_meshes: int = 64, tris_per_mesh: int = 156250, s: float = 0.025, seed: int = 100):
     """Config C5: n_meshes soups, each scaled into a cell of a 4x4x4 lattice
     spanning [-5,5]^3 with a seeded rigid rotation, flattened to world space

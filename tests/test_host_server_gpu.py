@@ -20,7 +20,8 @@ def test_server_on_the_device_backend(built, mode):
         a, b = int(inst[i]["first_tri"]), int(inst[i]["first_tri"] + inst[i]["n_tris"])
         meshes.append((local[a:b], inst[i]["basis"], inst[i]["origin"], [0x1, 0x6, 0x80000001][i]))
     rays = np.concatenate([po.grid_rays((0, 0, -12), (0, 0, 1), 64, 48, 50.0), synth.incoherent_rays(3000, 5)])
-    sd.check(meshes, rays, 0xFFFFFFFF, mode=mode)    # >= 256 rays without the hint: Morton-sorted on the device
+    out = sd.check(meshes, rays, 0xFFFFFFFF, mode=mode)    # >= 256 rays without the hint: Morton-sorted on the device
+    assert out["header"][14] == 1, "this tier must run on the device"
     sd.check(meshes, rays, 0x4, mode=mode)           # only the second mesh is visible: the mask filters during traversal
     sd.check(meshes[:1], rays[:100], 0x1, mode=mode)  # below MIN_BATCH_FOR_SORTING
 
@@ -28,10 +29,12 @@ def test_server_on_the_device_backend(built, mode):
 def test_c1_cube_through_the_server_on_the_device(built):
     c1 = synth.CONFIGS["C1"]
     rays = po.grid_rays(c1["origin"], c1["forward"], *c1["grid"], c1["fov"])
-    sd.check([(synth.cube(), np.eye(3).reshape(9), (0, 0, 0), 0xFFFFFFFF)], rays, 0xFFFFFFFF, mode="gpu")
+    out = sd.check([(synth.cube(), np.eye(3).reshape(9), (0, 0, 0), 0xFFFFFFFF)], rays, 0xFFFFFFFF, mode="gpu")
+    assert out["header"][14] == 1
 
 
 def test_fallback_modes_use_the_device_when_there_is_one(built):
     v = synth.soup(800, 0.4, 31)
     rays = np.concatenate([po.grid_rays((0, 0, -12), (0, 0, 1), 24, 16, 50.0), synth.incoherent_rays(300, 3)])
-    sd.check([(v, np.eye(3).reshape(9), (0, 0, 0), 0xFFFFFFFF)], rays, 0xFFFFFFFF, mode="auto-fallback")
+    out = sd.check([(v, np.eye(3).reshape(9), (0, 0, 0), 0xFFFFFFFF)], rays, 0xFFFFFFFF, mode="auto-fallback")
+    assert out["header"][14] == 1 and (out["header"][15] & 1) == 0   # a device is there: nothing fell back
