@@ -358,7 +358,7 @@ int mrt_build_instanced_scene_device(mrt_ctx *ctx, const float *verts9, uint32_t
  * the mesh-local index; the reference's TLAS path reports the local index, SURVEY.md section 0
  * item 4), hit_layers = the instance's mask (whole instances are skipped by the query mask),
  * normal = normalize(basis * mesh-space normal), position on the world ray.  Every cast entry
- * point works on such a scene (one lane per ray); hit tokens do not (MRT_ERR_UNSUPPORTED).
+ * point works on such a scene; hit tokens are 8 bytes there ({triangle, instance}: mrt_token_bytes).
  * verts9 / instances: host arrays.  Transforms must be invertible (MRT_ERR_INVALID).
  * flags: 0, or MRT_BUILD_BLAS_ON_DEVICE to build the meshes' BVHs with the device builder of
  * mrt_build_scene_device (milliseconds instead of 0.3 s per million triangles; the same hit
@@ -370,6 +370,30 @@ int mrt_upload_two_level_scene(mrt_ctx *ctx, const float *verts9, uint32_t n_mes
  * instances (same meshes, same order) with new transforms / masks.  Only the top level is rebuilt
  * and re-uploaded (n_instances rows + fewer than 2 n_instances nodes). */
 int mrt_update_instances(mrt_ctx *ctx, const mrt_instance *instances, uint32_t n_instances);
+
+/* The prepared two-level scene ON THE HOST: exactly the arrays mrt_upload_two_level_scene uploads, for a host whose
+ * router also has a CPU backend (RayDispatcher::_cpu_cast_rays routes to the TLAS when there is one,
+ * src/dispatch/ray_dispatcher.h:443-452; the mirror's walk is csrc/host/cpu_backend.hpp, CpuTwoLevelWalker).  Host-only:
+ * no device, no context.  Layouts (all little-endian 32-bit words):
+ *   nodes      64-byte rows {lmin xyz, left ref | lmax xyz, right ref | rmin xyz, - | rmax xyz, -}; a ref < 0x7FFFFFFF is a
+ *              node index, a ref >= 0x80000000 a leaf: its low 31 bits = first row of a run of instances (TLAS,
+ *              nodes [0, n_tlas_nodes)) or of triangles (a BLAS); node 0 is the TLAS root
+ *   tri_hot    48-byte rows {v0 xyz, mesh-local id | e1 xyz, layers | e2 xyz, flags}; flags & 1 = last triangle of its leaf
+ *   tri_cold   16-byte rows {normal xyz, -} (mesh space)
+ *   instances  128-byte rows in TLAS leaf order: 12 floats inverse transform (rows {m00 m01 m02 t}), 9 floats basis,
+ *              u32 root node of the BLAS, u32 flat id of the instance's first triangle, u32 layer mask,
+ *              u32 flags (1 = last instance of its TLAS leaf), u32 registration index, 7 words unused */
+typedef struct mrt_two_level_host mrt_two_level_host;
+typedef struct mrt_two_level_arrays {
+	const mrt_bvh_node_wide64 *nodes; uint32_t n_nodes, n_tlas_nodes;
+	const float *tri_hot, *tri_cold; uint32_t n_tris;
+	const float *instances; uint32_t n_instances;
+	uint32_t depth;       /* stack entries one ray can need */
+} mrt_two_level_arrays;
+int mrt_two_level_prepare_host(const float *verts9, uint32_t n_mesh_tris, const mrt_instance *instances, uint32_t n_instances,
+		uint32_t n_threads, mrt_two_level_host **out);
+int mrt_two_level_host_arrays(const mrt_two_level_host *h, mrt_two_level_arrays *out);
+void mrt_two_level_free_host(mrt_two_level_host *h);
 
 int mrt_is_available(const mrt_ctx *ctx);      /* initialized && scene uploaded */
 int mrt_scene_info(const mrt_ctx *ctx, uint32_t *n_tris, uint32_t *n_wide_nodes, uint32_t *bvh_depth);

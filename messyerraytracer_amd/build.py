@@ -9,6 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmrt_hip.so")
 HOST_TEST = os.path.join(HERE, "host_mirror_test")
 HOST_CPU_TEST = os.path.join(HERE, "host_cpu_test")
+HOST_TLAS_TEST = os.path.join(HERE, "host_tlas_test")
 
 SOURCES = ["kernels.hip", "api.hip", "group.hip", "device_build.hip", "host/scene_prep.cpp", "host/bvh_builder.cpp",
            "host/two_level_prep.cpp"]
@@ -74,7 +75,21 @@ def build_host_cpu_test(force: bool = False) -> str:
     return HOST_CPU_TEST
 
 
+def build_host_tlas_test(force: bool = False) -> str:
+    """C++ test driver for the router with a TLAS set (two-level scenes on the CPU and the device backend)."""
+    src = os.path.join(CSRC, "host", "host_tlas_test.cpp")
+    deps = [src, LIB] + [os.path.join(CSRC, h) for h in HEADERS]
+    if force or _stale(HOST_TLAS_TEST, deps):
+        cmd = [_hipcc(), "-O2", "-std=c++17", "-ffp-contract=off", "-Wall", src, "-o", HOST_TLAS_TEST,
+               "-L" + HERE, "-lmrt_hip", "-Wl,-rpath," + HERE, "-pthread"]
+        r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+        if r.returncode != 0:
+            raise RuntimeError("host tlas test build failed:\n" + r.stdout + r.stderr)
+    return HOST_TLAS_TEST
+
+
 if __name__ == "__main__":
     print(build_lib(force=True, verbose=True))
     print(build_host_test(force=True))
     print(build_host_cpu_test(force=True))
+    print(build_host_tlas_test(force=True))

@@ -28,7 +28,7 @@ KERNEL_TWO_LEVEL, KERNEL_TWO_LEVEL_PACKET, KERNEL_TWO_LEVEL_PERSISTENT, KERNEL_T
 SYMBOLS = [
     "mrt_create", "mrt_destroy", "mrt_last_error", "mrt_status_string", "mrt_version", "mrt_set_stream",
     "mrt_synchronize", "mrt_make_triangles", "mrt_pack_host_triangles", "mrt_bvh2_build", "mrt_bvh2_save", "mrt_bvh2_load", "mrt_upload_scene",
-    "mrt_build_scene_device", "mrt_flatten_instances", "mrt_build_instanced_scene_device", "mrt_upload_two_level_scene", "mrt_update_instances", "mrt_is_available", "mrt_scene_info", "mrt_cast", "mrt_submit", "mrt_collect", "mrt_has_pending",
+    "mrt_build_scene_device", "mrt_flatten_instances", "mrt_build_instanced_scene_device", "mrt_upload_two_level_scene", "mrt_update_instances", "mrt_two_level_prepare_host", "mrt_two_level_host_arrays", "mrt_two_level_free_host", "mrt_is_available", "mrt_scene_info", "mrt_cast", "mrt_submit", "mrt_collect", "mrt_has_pending",
     "mrt_camera_look", "mrt_camera_perspective", "mrt_camera_orthographic", "mrt_generate_grid", "mrt_cast_grid", "mrt_cast_tiled", "mrt_expand_tokens",
     "mrt_expand_grid_tokens", "mrt_token_bytes", "mrt_morton_keys",
     "mrt_kernel_name", "mrt_struct_size", "mrt_get_stats", "mrt_last_kernel_variant", "mrt_device_alloc", "mrt_device_free", "mrt_memcpy_h2d", "mrt_memcpy_d2h",

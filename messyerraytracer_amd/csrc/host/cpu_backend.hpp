@@ -19,6 +19,7 @@
 #include <cmath>
 #include <condition_variable>
 #include <cstdint>
+#include <cstring>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -223,6 +224,155 @@ private:
 		const float x0 = std::fmaf(b.aabb_min[0], ix, nrx), x1 = std::fmaf(b.aabb_max[0], ix, nrx);
 		const float y0 = std::fmaf(b.aabb_min[1], iy, nry), y1 = std::fmaf(b.aabb_max[1], iy, nry);
 		const float z0 = std::fmaf(b.aabb_min[2], iz, nrz), z1 = std::fmaf(b.aabb_max[2], iz, nrz);
+		tnear = std::fmax(std::fmax(std::fmin(x0, x1), std::fmin(y0, y1)), std::fmax(std::fmin(z0, z1), t_min));
+		const float tfar = std::fmin(std::fmin(std::fmax(x0, x1), std::fmax(y0, y1)), std::fmin(std::fmax(z0, z1), best_t));
+		return tnear <= tfar;
+	}
+};
+
+// One ray against a two-level scene on the host: SceneTLAS::cast_ray / any_hit (src/accel/scene_tlas.h:198-251 =
+// tinybvh::BVH::IntersectTLAS, tiny_bvh.h:3306-3380) as the DEVICE walks it (csrc/two_level_kernel.h,
+// trace_two_level_kernel, restated one ray at a time): one node array for the TLAS and every BLAS, one stack; at a TLAS
+// leaf the rest of the leaf is pushed, the ray goes to the instance's mesh space (o' = M o + t, d' = M d, no
+// renormalisation: t stays world-parameterised), a return marker is pushed and the walk continues at the BLAS root; popping
+// the marker restores the world ray.  Same fused operations, same acceptance rules, an exact tie to the lower FLAT id,
+// whole instances skipped by the query mask: the records equal the device's bit for bit.  The arrays are the ones
+// mrt_upload_two_level_scene uploads (mrt_two_level_prepare_host, include/mrt_hip.h).
+class CpuTwoLevelWalker {
+public:
+	explicit CpuTwoLevelWalker(const mrt_two_level_arrays &a) : a_(a) {}
+
+	Intersection cast(const Ray &ray, uint32_t query_mask, bool any_hit, RayStats *stats) const
+	{
+		Intersection out;
+		if (stats) stats->rays_cast++;
+		if (a_.n_instances == 0 || ray.t_min >= ray.t_max) return out;
+		constexpr uint32_t kEnd = 0x7FFFFFFFu, kBack = 0x7FFFFFFEu, kLeaf = 0x80000000u; // sentinel, "back to the world ray", leaf flag
+		const float wox = ray.origin.x, woy = ray.origin.y, woz = ray.origin.z, wdx = ray.direction.x, wdy = ray.direction.y, wdz = ray.direction.z;
+		float ox = wox, oy = woy, oz = woz, dx = wdx, dy = wdy, dz = wdz;          // the ray being walked
+		float ix = safe_inv(dx), iy = safe_inv(dy), iz = safe_inv(dz);
+		float nrx = -(ox * ix), nry = -(oy * iy), nrz = -(oz * iz);
+		float best_t = ray.t_max, best_u = 0.0f, best_v = 0.0f;
+		uint32_t best_slot = UINT32_MAX, best_id = UINT32_MAX, best_inst = 0u;
+		std::vector<uint32_t> stack(a_.depth + 8u);
+		uint32_t sp = 0;
+		stack[sp++] = kEnd;
+		uint32_t cur = 0, id_base = 0u, cur_inst = 0u;
+		bool in_blas = false;
+		while (cur != kEnd) {
+			if (cur < kBack) { // an inner node of the TLAS or of a BLAS
+				if (stats) stats->bvh_nodes_visited++;
+				const mrt_bvh_node_wide64 &n = a_.nodes[cur];
+				float tl, tr;
+				const bool hl = slab(n.left_min, n.left_max, ix, iy, iz, nrx, nry, nrz, ray.t_min, best_t, tl);
+				const bool hr = slab(n.right_min, n.right_max, ix, iy, iz, nrx, nry, nrz, ray.t_min, best_t, tr);
+				if (hl && hr) {
+					const bool left_near = tl < tr;
+					cur = left_near ? n.left_idx : n.right_idx;
+					if (sp < stack.size()) stack[sp++] = left_near ? n.right_idx : n.left_idx;
+				} else if (hl) cur = n.left_idx;
+				else if (hr) cur = n.right_idx;
+				else cur = stack[--sp];
+				continue;
+			}
+			if (cur == kBack) { // the BLAS is done: back to the world ray
+				ox = wox; oy = woy; oz = woz; dx = wdx; dy = wdy; dz = wdz;
+				ix = safe_inv(dx); iy = safe_inv(dy); iz = safe_inv(dz);
+				nrx = -(ox * ix); nry = -(oy * iy); nrz = -(oz * iz);
+				in_blas = false;
+				cur = stack[--sp];
+				continue;
+			}
+			const uint32_t slot0 = cur & 0x7FFFFFFFu;
+			if (!in_blas) { // TLAS leaf: a run of instances, one at a time
+				const float *row = a_.instances + (size_t)slot0 * 32u;
+				uint32_t meta[4], flags;
+				std::memcpy(meta, row + 20, sizeof(meta)); // {basis[8], root, id_base, layers}
+				std::memcpy(&flags, row + 24, sizeof(flags));
+				if ((flags & 1u) == 0u && sp < stack.size()) stack[sp++] = kLeaf | (slot0 + 1u); // the rest of the leaf
+				if ((meta[3] & query_mask) != 0u) {
+					ox = std::fmaf(row[0], wox, std::fmaf(row[1], woy, std::fmaf(row[2], woz, row[3])));
+					oy = std::fmaf(row[4], wox, std::fmaf(row[5], woy, std::fmaf(row[6], woz, row[7])));
+					oz = std::fmaf(row[8], wox, std::fmaf(row[9], woy, std::fmaf(row[10], woz, row[11])));
+					dx = std::fmaf(row[0], wdx, std::fmaf(row[1], wdy, row[2] * wdz));
+					dy = std::fmaf(row[4], wdx, std::fmaf(row[5], wdy, row[6] * wdz));
+					dz = std::fmaf(row[8], wdx, std::fmaf(row[9], wdy, row[10] * wdz));
+					ix = safe_inv(dx); iy = safe_inv(dy); iz = safe_inv(dz);
+					nrx = -(ox * ix); nry = -(oy * iy); nrz = -(oz * iz);
+					if (sp < stack.size()) stack[sp++] = kBack;
+					in_blas = true; cur_inst = slot0; id_base = meta[2];
+					cur = meta[1];
+				} else cur = stack[--sp];
+				continue;
+			}
+			// BLAS leaf: its triangles, on the mesh-space ray
+			uint32_t slot = slot0;
+			bool last;
+			do {
+				const float *q = a_.tri_hot + (size_t)slot * 12u; // {v0, id | e1, layers | e2, flags}
+				uint32_t local_id, tflags;
+				std::memcpy(&local_id, q + 3, 4); std::memcpy(&tflags, q + 11, 4);
+				last = (tflags & 1u) != 0u;
+				if (stats) stats->tri_tests++;
+				const float pvx = std::fmaf(dy, q[10], -(dz * q[9]));
+				const float pvy = std::fmaf(dz, q[8], -(dx * q[10]));
+				const float pvz = std::fmaf(dx, q[9], -(dy * q[8]));
+				const float det = dot3(q[4], q[5], q[6], pvx, pvy, pvz);
+				if (!(std::fabs(det) < 1e-8f)) {
+					const float inv_det = 1.0f / det;
+					const float tvx = ox - q[0], tvy = oy - q[1], tvz = oz - q[2];
+					const float u = dot3(tvx, tvy, tvz, pvx, pvy, pvz) * inv_det;
+					if (!(u < 0.0f || u > 1.0f)) {
+						const float qvx = std::fmaf(tvy, q[6], -(tvz * q[5]));
+						const float qvy = std::fmaf(tvz, q[4], -(tvx * q[6]));
+						const float qvz = std::fmaf(tvx, q[5], -(tvy * q[4]));
+						const float v = dot3(dx, dy, dz, qvx, qvy, qvz) * inv_det;
+						if (!(v < 0.0f || u + v > 1.0f)) {
+							const float t = dot3(q[8], q[9], q[10], qvx, qvy, qvz) * inv_det;
+							const uint32_t id = id_base + local_id;
+							if (!(t < ray.t_min) && (t < best_t || (t == best_t && best_slot != UINT32_MAX && id < best_id))) {
+								best_t = t; best_u = u; best_v = v; best_slot = slot; best_id = id; best_inst = cur_inst;
+								if (any_hit) last = true;
+							}
+						}
+					}
+				}
+				slot++;
+			} while (!last);
+			if (any_hit && best_slot != UINT32_MAX) break;
+			cur = stack[--sp];
+		}
+		if (best_slot != UINT32_MAX) { // SceneTLAS::cast_ray, scene_tlas.h:217-244, with the flat id
+			const float *row = a_.instances + (size_t)best_inst * 32u, *b = row + 12, *no = a_.tri_cold + (size_t)best_slot * 4u;
+			uint32_t layers;
+			std::memcpy(&layers, row + 23, 4);
+			float nx = std::fmaf(b[0], no[0], std::fmaf(b[1], no[1], b[2] * no[2]));
+			float ny = std::fmaf(b[3], no[0], std::fmaf(b[4], no[1], b[5] * no[2]));
+			float nz = std::fmaf(b[6], no[0], std::fmaf(b[7], no[1], b[8] * no[2]));
+			const float l2 = std::fmaf(nx, nx, std::fmaf(ny, ny, nz * nz));
+			if (l2 == 0.0f) { nx = ny = nz = 0.0f; }
+			else { const float l = std::sqrt(l2); nx /= l; ny /= l; nz /= l; }
+			out.t = best_t;
+			out.position = Vector3(wox + wdx * best_t, woy + wdy * best_t, woz + wdz * best_t);
+			out.normal = Vector3(nx, ny, nz); out.u = best_u; out.v = best_v; out.prim_id = best_id; out.hit_layers = layers;
+			if (stats) stats->hits++;
+		}
+		return out;
+	}
+
+private:
+	mrt_two_level_arrays a_;
+	static float safe_inv(float d)
+	{
+		const float eps = 1e-9f, big = 1.0f / eps;
+		return std::fabs(d) > eps ? 1.0f / d : (d >= 0.0f ? big : -big);
+	}
+	static float dot3(float ax, float ay, float az, float bx, float by, float bz) { return std::fmaf(ax, bx, std::fmaf(ay, by, az * bz)); }
+	static bool slab(const float mn[3], const float mx[3], float ix, float iy, float iz, float nrx, float nry, float nrz, float t_min, float best_t, float &tnear)
+	{
+		const float x0 = std::fmaf(mn[0], ix, nrx), x1 = std::fmaf(mx[0], ix, nrx);
+		const float y0 = std::fmaf(mn[1], iy, nry), y1 = std::fmaf(mx[1], iy, nry);
+		const float z0 = std::fmaf(mn[2], iz, nrz), z1 = std::fmaf(mx[2], iz, nrz);
 		tnear = std::fmax(std::fmax(std::fmin(x0, x1), std::fmin(y0, y1)), std::fmax(std::fmin(z0, z1), t_min));
 		const float tfar = std::fmin(std::fmin(std::fmax(x0, x1), std::fmax(y0, y1)), std::fmin(std::fmax(z0, z1), best_t));
 		return tnear <= tfar;

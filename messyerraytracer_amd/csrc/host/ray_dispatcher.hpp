@@ -56,12 +56,46 @@ struct RayScene {
 	int triangle_count() const { return (int)triangles.size(); }
 };
 
+// SceneTLAS (src/accel/scene_tlas.h:140-251) with its MeshBLAS / BLASInstance parts (mesh_blas.h:86-138,
+// blas_instance.h:47-107): mesh-space triangles stored once, placed instances on top.  build_tlas() prepares the
+// two-level arrays on the host (one binned-SAH BVH per distinct mesh, one over the instances' world boxes: exactly what
+// the device is fed); set_instance_transform + refit_tlas = new transforms, meshes untouched.
+struct SceneTLAS {
+	std::vector<float> mesh_vertices;        // 9 floats per triangle, mesh space, all meshes back to back
+	std::vector<mrt_instance> instances;     // the mesh (first_tri, n_tris), its Transform3D and layer mask, in registration order
+	SceneTLAS() = default;
+	SceneTLAS(const SceneTLAS &) = delete;
+	SceneTLAS &operator=(const SceneTLAS &) = delete;
+	~SceneTLAS() { clear_built(); }
+	bool build_tlas(uint32_t n_threads = 0)
+	{
+		clear_built();
+		if (instances.empty() || mesh_vertices.empty()) return false;
+		if (mrt_two_level_prepare_host(mesh_vertices.data(), (uint32_t)(mesh_vertices.size() / 9), instances.data(), (uint32_t)instances.size(),
+				n_threads, &host_) != MRT_OK) return false;
+		return mrt_two_level_host_arrays(host_, &arrays_) == MRT_OK;
+	}
+	bool is_built() const { return host_ != nullptr; }
+	const mrt_two_level_arrays &arrays() const { return arrays_; }
+	int instance_count() const { return (int)instances.size(); }
+
+private:
+	mrt_two_level_host *host_ = nullptr;
+	mrt_two_level_arrays arrays_{};
+	void clear_built() { if (host_) { mrt_two_level_free_host(host_); host_ = nullptr; } arrays_ = mrt_two_level_arrays{}; }
+};
+
 class RayDispatcher {
 public:
 	enum class Backend { CPU, GPU, AUTO }; // ray_dispatcher.h:40-44
 
 	RayScene &scene() { return scene_; }
 	const RayScene &scene() const { return scene_; }
+
+	// ray_dispatcher.h:82-88: with a TLAS set, the CPU path walks the two-level scene (_cpu_cast_rays, :443-452); here the
+	// device backend does too (the scene is uploaded as a two-level scene: nothing flattened).  nullptr = flat scene again.
+	void set_tlas(SceneTLAS *tlas) { tlas_ = tlas; }
+	bool has_tlas() const { return tlas_ != nullptr && tlas_->is_built(); }
 
 	void build() // ray_dispatcher.h:67-80
 	{
@@ -84,7 +118,9 @@ public:
 	bool initialize_gpu(int device_ordinal = 0) { return gpu_caster_.initialize(device_ordinal); }
 	void upload_to_gpu() // ray_dispatcher.h:99-107
 	{
-		if (gpu_caster_.is_initialized() && scene_.built)
+		if (gpu_caster_.is_initialized() && has_tlas())
+			gpu_caster_.upload_two_level_scene(tlas_->mesh_vertices.data(), (uint32_t)(tlas_->mesh_vertices.size() / 9), tlas_->instances);
+		else if (gpu_caster_.is_initialized() && scene_.built)
 			gpu_caster_.upload_scene(scene_.triangles, scene_.bvh2.data(), scene_.used_nodes, scene_.prim_idx.data());
 	}
 	bool using_gpu() const { return _should_use_gpu() && gpu_caster_.is_available(); }
@@ -96,7 +132,7 @@ public:
 		if (count < 0 || (count > 0 && (!rays || !results))) return MRT_ERR_INVALID;
 		if (count == 0) return MRT_OK; // a silent no-op on every backend (gpu_ray_caster.cpp:419)
 		if (_route_to_cpu("cast_rays")) {
-			return _cpu_dispatch(count, stats, [&](const CpuWalker &w, int i, RayStats *s) { results[i] = w.cast(rays[i], query_mask, false, s); });
+			return _cpu_dispatch(count, stats, [&](const auto &w, int i, RayStats *s) { results[i] = w.cast(rays[i], query_mask, false, s); });
 		}
 		if (!using_gpu()) return MRT_ERR_NO_DEVICE;
 		if (!coherent && count >= MIN_BATCH_FOR_SORTING) gpu_caster_.cast_rays_sorted(rays, results, count, query_mask);
@@ -111,7 +147,7 @@ public:
 		if (count < 0 || (count > 0 && (!rays || !hit_results))) return MRT_ERR_INVALID;
 		if (count == 0) return MRT_OK;
 		if (_route_to_cpu("any_hit_rays")) {
-			return _cpu_dispatch(count, stats, [&](const CpuWalker &w, int i, RayStats *s) { hit_results[i] = w.cast(rays[i], query_mask, true, s).hit(); });
+			return _cpu_dispatch(count, stats, [&](const auto &w, int i, RayStats *s) { hit_results[i] = w.cast(rays[i], query_mask, true, s).hit(); });
 		}
 		if (!using_gpu()) return MRT_ERR_NO_DEVICE;
 		if (!coherent && count >= MIN_BATCH_FOR_SORTING) gpu_caster_.cast_rays_any_hit_sorted(rays, hit_results, count, query_mask);
@@ -123,14 +159,20 @@ public:
 	Intersection cast_ray(const Ray &ray, RayStats *stats = nullptr, uint32_t query_mask = 0xFFFFFFFF)
 	{
 		Intersection result;
-		if (_route_to_cpu("cast_ray")) { if (scene_.built) result = _walker().cast(ray, query_mask, false, stats); }
+		if (_route_to_cpu("cast_ray")) {
+			if (has_tlas()) result = CpuTwoLevelWalker(tlas_->arrays()).cast(ray, query_mask, false, stats);
+			else if (scene_.built) result = _walker().cast(ray, query_mask, false, stats);
+		}
 		else if (using_gpu()) { gpu_caster_.cast_rays(&ray, &result, 1, query_mask); if (stats) stats->rays_cast++; }
 		return result;
 	}
 	bool any_hit(const Ray &ray, RayStats *stats = nullptr, uint32_t query_mask = 0xFFFFFFFF)
 	{
 		bool result = false;
-		if (_route_to_cpu("any_hit")) { if (scene_.built) result = _walker().cast(ray, query_mask, true, stats).hit(); }
+		if (_route_to_cpu("any_hit")) {
+			if (has_tlas()) result = CpuTwoLevelWalker(tlas_->arrays()).cast(ray, query_mask, true, stats).hit();
+			else if (scene_.built) result = _walker().cast(ray, query_mask, true, stats).hit();
+		}
 		else if (using_gpu()) { gpu_caster_.cast_rays_any_hit(&ray, &result, 1, query_mask); if (stats) stats->rays_cast++; }
 		return result;
 	}
@@ -168,6 +210,7 @@ public:
 
 private:
 	RayScene scene_;
+	SceneTLAS *tlas_ = nullptr;  // not owned (ray_dispatcher.h:405)
 	GPURayCaster gpu_caster_;
 	ThreadPool pool_;            // persistent worker threads of the CPU backend (ray_dispatcher.h:403)
 	Backend backend_ = Backend::CPU;
@@ -186,8 +229,13 @@ private:
 	int _cpu_dispatch(int count, RayStats *stats, PerRay per_ray)
 	{
 		if (count == 0) return MRT_OK;
+		if (has_tlas()) return _cpu_run(CpuTwoLevelWalker(tlas_->arrays()), count, stats, per_ray); // ray_dispatcher.h:447-449
 		if (!scene_.built) { std::fprintf(stderr, "[RayDispatcher] CPU backend: no scene built\n"); return MRT_ERR_NO_SCENE; }
-		const CpuWalker w = _walker();
+		return _cpu_run(_walker(), count, stats, per_ray);
+	}
+	template <typename Walker, typename PerRay>
+	int _cpu_run(const Walker &w, int count, RayStats *stats, PerRay per_ray)
+	{
 		// one tally per span of the pool's split (at most helpers + 1), handed out in arrival order, summed at the end
 		std::vector<RayStats> tallies(stats ? pool_.thread_count() + 1 : 0);
 		std::atomic<uint32_t> tally_cursor{0};

@@ -12,6 +12,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <new>
 #include <utility>
 #include <vector>
 
@@ -273,3 +274,44 @@ int prepare_two_level(const float *verts9, uint32_t n_mesh_tris, const mrt_insta
 }
 
 } // namespace mrt
+
+// ---- the prepared scene on the host, through the C-ABI (include/mrt_hip.h: mrt_two_level_prepare_host) ----------------
+struct mrt_two_level_host { mrt::TwoLevelHost h; };
+
+extern "C" {
+
+int mrt_two_level_prepare_host(const float *verts9, uint32_t n_mesh_tris, const mrt_instance *instances, uint32_t n_instances,
+		uint32_t n_threads, mrt_two_level_host **out)
+{
+	if (!out) return MRT_ERR_INVALID;
+	*out = nullptr;
+	if (!verts9 || !instances || n_instances == 0 || n_mesh_tris == 0) return MRT_ERR_INVALID;
+	mrt_two_level_host *w = new (std::nothrow) mrt_two_level_host();
+	if (!w) return MRT_ERR_OOM;
+	char err[256];
+	const int rc = mrt::prepare_two_level(verts9, n_mesh_tris, instances, n_instances, n_threads, true, &w->h, err, sizeof(err));
+	if (rc != MRT_OK) { mrt::free_two_level(&w->h); delete w; return rc; }
+	*out = w;
+	return MRT_OK;
+}
+
+int mrt_two_level_host_arrays(const mrt_two_level_host *w, mrt_two_level_arrays *out)
+{
+	if (!w || !out) return MRT_ERR_INVALID;
+	static_assert(sizeof(mrt::DevNode) == sizeof(mrt_bvh_node_wide64), "the device node is the wide node");
+	out->nodes = reinterpret_cast<const mrt_bvh_node_wide64 *>(w->h.nodes); out->n_nodes = w->h.n_nodes; out->n_tlas_nodes = w->h.n_tlas_nodes;
+	out->tri_hot = reinterpret_cast<const float *>(w->h.hot); out->tri_cold = reinterpret_cast<const float *>(w->h.cold); out->n_tris = w->h.n_tris;
+	out->instances = reinterpret_cast<const float *>(w->h.inst); out->n_instances = w->h.n_inst;
+	out->depth = w->h.depth;
+	return MRT_OK;
+}
+
+void mrt_two_level_free_host(mrt_two_level_host *w)
+{
+	if (!w) return;
+	mrt::free_two_level(&w->h);
+	delete w;
+}
+
+} // extern "C"
+

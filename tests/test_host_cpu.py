@@ -52,3 +52,19 @@ def test_opt_in_fallback_to_the_cpu_pool(built):
     mesh = [(v, np.eye(3).reshape(9), (0, 0, 0), 0xFFFFFFFF)]
     sd.check(mesh, rays, 0xFFFFFFFF, mode="auto-fallback")
     sd.check(mesh, rays, 0xFFFFFFFF, mode="gpu-fallback")
+
+
+def test_cpu_backend_routes_to_the_tlas(built):
+    """ray_dispatcher.h:443-452: with a TLAS set the CPU path walks the two-level scene.  Meshes placed twice with different
+    masks, 5 000 rays (range-split over the pool), masks that hide whole instances: the records of the oracle's SceneTLAS
+    restatement -- flat ids (instance id base + mesh-local index), the instance's layer mask, normalize(basis n)."""
+    local, inst = synth.multi_mesh_instances(4, 900, 0.3, 21)
+    extra = inst[[1]].copy()
+    extra["origin"] += np.float32([0.6, 0.2, -0.8])
+    extra["layers"] = 0x4
+    inst = np.concatenate([inst, extra])
+    inst["layers"][:4] = [0x1, 0x2, 0x1, 0x80000000]
+    rays = np.concatenate([po.grid_rays((0, 0, -12), (0, 0, 1), 64, 48, 50.0), synth.incoherent_rays(2000, 13)])
+    sd.check_tlas(local, inst, rays, 0xFFFFFFFF)
+    sd.check_tlas(local, inst, rays, 0x4)            # only the second placement of mesh 1
+    sd.check_tlas(local, inst[:1], rays[:90], 0x1)   # one instance, below the threading threshold

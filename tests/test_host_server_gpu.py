@@ -38,3 +38,18 @@ def test_fallback_modes_use_the_device_when_there_is_one(built):
     rays = np.concatenate([po.grid_rays((0, 0, -12), (0, 0, 1), 24, 16, 50.0), synth.incoherent_rays(300, 3)])
     out = sd.check([(v, np.eye(3).reshape(9), (0, 0, 0), 0xFFFFFFFF)], rays, 0xFFFFFFFF, mode="auto-fallback")
     assert out["header"][14] == 1 and (out["header"][15] & 1) == 0   # a device is there: nothing fell back
+
+
+def test_router_with_a_tlas_on_the_device_backend(built):
+    """RayDispatcher::set_tlas + Backend::GPU: the scene is uploaded as a two-level scene (nothing flattened) and every cast
+    entry point of the router returns the oracle's SceneTLAS records; the same driver on Backend::CPU returns the same bytes."""
+    local, inst = synth.multi_mesh_instances(4, 900, 0.3, 21)
+    extra = inst[[1]].copy()
+    extra["origin"] += np.float32([0.6, 0.2, -0.8])
+    extra["layers"] = 0x4
+    inst = np.concatenate([inst, extra])
+    rays = np.concatenate([po.grid_rays((0, 0, -12), (0, 0, 1), 64, 48, 50.0), synth.incoherent_rays(2000, 13)])
+    on_gpu = sd.check_tlas(local, inst, rays, 0xFFFFFFFF, mode="gpu")
+    on_cpu = sd.check_tlas(local, inst, rays, 0xFFFFFFFF, mode="cpu")
+    assert on_gpu["nearest"].tobytes() == on_cpu["nearest"].tobytes()
+    sd.check_tlas(local, inst, rays, 0x4, mode="gpu")
