@@ -48,7 +48,7 @@ class Options(C.Structure):
                 ("sort_threshold", C.c_uint32), ("grid_tile", C.c_uint32), ("tile_w_log2", C.c_uint32),
                 ("xcd_swizzle", C.c_uint32), ("stack_override", C.c_uint32), ("tile_order", C.c_uint32),
                 ("sort_key", C.c_uint32), ("refill", C.c_uint32), ("leaf_wait", C.c_uint32),
-                ("extra_lds", C.c_uint32), ("packet_wg", C.c_uint32), ("packet_cull", C.c_uint32), ("reserved", C.c_uint32 * 1)]
+                ("extra_lds", C.c_uint32), ("packet_wg", C.c_uint32), ("packet_cull", C.c_uint32), ("tile_schedule", C.c_uint32)]
 
 
 class Camera(C.Structure):
@@ -243,7 +243,7 @@ class Context:
     def __init__(self, device: int = 0, kernel: int = KERNEL_AUTO, count_visits: bool = False,
                  sort_threshold: int = 0, grid_tile: int = 0, tile_w_log2: int = 0, xcd_swizzle: int = 0,
                  stack_override: int = 0, tile_order: int = 0, sort_key: int = 0, refill: int = 0,
-                 leaf_wait: int = 0, extra_lds: int = 0, packet_wg: int = 0, packet_cull: int = 0):
+                 leaf_wait: int = 0, extra_lds: int = 0, packet_wg: int = 0, packet_cull: int = 0, tile_schedule: int = 0):
         self.L = load()
         opts = Options()
         opts.struct_size = C.sizeof(Options)
@@ -261,6 +261,7 @@ class Context:
         opts.extra_lds = extra_lds
         opts.packet_wg = packet_wg
         opts.packet_cull = packet_cull
+        opts.tile_schedule = tile_schedule
         self.h = C.c_void_p()
         rc = self.L.mrt_create(device, C.byref(opts), C.byref(self.h))
         if rc:

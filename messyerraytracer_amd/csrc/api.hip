@@ -77,6 +77,26 @@ struct mrt_ctx {
 	// small host-array casts (RayDispatcher::cast_ray / any_hit: one ray; tiles of a few hundred rays): rays and hits go
 	// through two pinned, device-mapped buffers instead of two DMA copies (mrt_cast)
 	void *h_small_in = nullptr, *d_small_in = nullptr, *h_small_out = nullptr, *d_small_out = nullptr;
+	// Frame-coherent tile schedule of grid casts: what every schedule unit (one 8x8 tile, or the two of a 128-ray wave)
+	// cost in the last cast of this grid, and the launch order made of it (longest first); see schedule_grid().
+	struct TileSchedule {
+		uint32_t grid_w = 0, grid_h = 0, y0 = 0, rows = 0, unit = 0, n_units = 0, tile_w_log2 = 0;
+		// two generations: frame f notes its costs in cost[f & 1] and the side stream sorts them into order[f & 1] while frame
+		// f + 1 (launched in the order of frame f - 1) already runs: back-to-back frames never wait for a sort
+		uint32_t frame = 0, gen = 0;       // frames of this grid, sorts issued for it
+		bool measuring = false;            // this frame notes its costs (and is sorted afterwards)
+		bool have_order[2] = {false, false};
+		DevBuf cost[2], order[2], cost_sorted, iota, tmp;
+		hipStream_t side = nullptr;
+		hipEvent_t traced = nullptr, ready[2] = {nullptr, nullptr};
+		void forget() { have_order[0] = have_order[1] = false; }
+	} sched;
+	// Which of the two packet kernels a mid-size grid takes is MEASURED per grid (tune_grid_kernel): frames 0-2 run the 64-ray
+	// kernel (plain order, then scheduled), frames 3-5 the 128-ray walk, and from frame 6 on the faster of the two third
+	// frames is kept (the better one flips with the number of rounds a grid makes on the chip: 1280x960 0.33 against 0.37 ms
+	// for the 128-ray walk, 1920x1080 0.59 against 0.44).
+	uint64_t last_detect_count = 0;   // rays of the last cast whose row width was looked for on the device (h_auto holds what it found)
+	struct GridTune { uint32_t grid_w = 0, grid_h = 0, y0 = 0, rows = 0; int mode = -1; int phase = 0; float t_asm = 0.0f, t_dual = 0.0f; bool armed = false; } tune;
 	char queued_variant[96] = "", queued_alt_variant[96] = "", last_variant[96] = ""; // instantiation names (mrt_last_kernel_variant)
 	uint32_t queued_kernel = 0, queued_alt_kernel = 0; bool queued_detect = false; // what the last enqueue_cast put on the stream
 	// host-array pipeline (cast_host_pipelined): copy streams and per-chunk events, created on first use
@@ -140,6 +160,7 @@ void free_scene(mrt_ctx *ctx)
 	ctx->d_nodes = nullptr; ctx->d_hot = nullptr; ctx->d_cold = nullptr; ctx->d_nodes4 = nullptr; ctx->d_nodes8 = nullptr;
 	ctx->n_nodes8 = ctx->stack8 = 0;
 	ctx->scene = false; ctx->n_nodes = ctx->n_tris = 0;
+	ctx->sched.forget(); ctx->tune.phase = 0; ctx->tune.mode = -1; // what was learnt about the old scene's grids
 }
 
 size_t ray_stride(uint32_t flags) { return (flags & MRT_FLAG_HOST_LAYOUT) ? sizeof(mrt_host_ray60) : sizeof(mrt_ray32); }
@@ -178,7 +199,10 @@ void base_params(mrt_ctx *ctx, mrt::TraceParams &p)
 	if (ctx->opts.tile_order == 4) p.tile_order = 3u; // column strips per XCD (kernels.hip, xcd_strips)
 	p.extra_lds = ctx->opts.extra_lds <= 60000u ? ctx->opts.extra_lds : 60000u;
 	p.count_mode = ctx->opts.count_visits;
-	p.rows_cull = ctx->opts.packet_cull == 1u ? 0u : 1u; // on by default since round 3 (one lane-row load a step ahead + DPP reduction: C3 -1.5 %, C5 -3 %; packet_rows_kernel.h)
+	// packet-level frustum culling in the 128-ray walk (packet_rows_kernel.h): 0 off, 1 on, 2 = by where the rays come from
+	// (launch_trace): on for rays generated in the kernel (C3 1.84 against 1.86 ms, C5 20.4 against 21.1), off for rays read from
+	// memory, where the walk with the scalar-cache prefetch waits less (C3 1.89 against 1.93 ms; profiles/r03_cull_cast_vs_fused.txt)
+	p.rows_cull = ctx->opts.packet_cull == 1u ? 0u : (ctx->opts.packet_cull == 2u ? 1u : 2u);
 	p.scene_abs_max = 0.0f;
 	for (int c = 0; c < 3; c++) p.scene_abs_max = std::fmax(p.scene_abs_max, std::fmax(std::fabs(ctx->bounds_lo[c]), std::fabs(ctx->bounds_hi[c])));
 	p.rows_wg = ctx->opts.packet_wg == 64u || ctx->opts.packet_wg == 256u ? ctx->opts.packet_wg : (scene_bytes > (size_t)256 << 20 ? 256u : 64u);
@@ -259,6 +283,13 @@ int device_sort(mrt_ctx *ctx, const void *d_rays, uint32_t in_fmt, uint64_t coun
 	*perm = io;
 	return MRT_OK;
 }
+
+} // namespace
+// (defined with the grid casts below)
+static bool schedule_applies(const mrt_ctx *ctx, const mrt::TraceParams &p);
+static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p);
+static int schedule_sort(mrt_ctx *ctx);
+namespace {
 
 // Lane kernel launch: plain (one fixed ray per lane) or persistent (resident waves pulling rays
 // from a counter, short LDS stack with HBM spill).
@@ -357,6 +388,16 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	}
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));
 	const bool any = mode == MRT_MODE_ANY_HIT;
+	// the tile schedule for a batch whose width the device finds: sized from what the previous cast of as many rays found
+	bool scheduled = false;
+	if (detect && !ctx->pending && ctx->last_detect_count == count && ctx->h_auto[0] != 0u && ctx->h_auto[3] == 0u && schedule_applies(ctx, p)) {
+		mrt::TraceParams g = p;
+		g.grid_w = ctx->h_auto[0]; g.rows = ctx->h_auto[1]; g.grid_h = g.rows; g.y0 = 0; g.tiles_x = ctx->h_auto[2];
+		if ((rc = schedule_grid(ctx, g))) return rc;
+		p.tile_sched = g.tile_sched; p.tile_cost = g.tile_cost; p.tile_unit = g.tile_unit; p.n_units = g.n_units;
+		scheduled = true;
+	}
+	ctx->last_detect_count = detect ? count : 0;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	ctx->queued_detect = detect; ctx->queued_alt_kernel = 0;
 	if (detect && ctx->opts.kernel == MRT_KERNEL_AUTO && !ctx->opts.count_visits && p.kernel != MRT_KERNEL_LANE && p.kernel != mrt::MRT_KERNEL_TWO_LEVEL) {
@@ -385,6 +426,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 		}
 	}
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+	if (scheduled && (rc = schedule_sort(ctx))) return rc;
 	ctx->stats.last_kernel_launches = sort ? 3 : (detect ? 2 : 1);
 	ctx->stats.rays_cast += count;
 	*d_hits_out = d_hits;
@@ -543,7 +585,7 @@ int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
 	if (!out) return MRT_ERR_INVALID;
 	*out = nullptr;
 	if (opts && opts->struct_size != sizeof(mrt_options)) return MRT_ERR_INVALID;
-	if (opts && ((opts->packet_wg != 0u && opts->packet_wg != 64u && opts->packet_wg != 256u) || opts->packet_cull > 2u || opts->kernel > MRT_KERNEL_PACKET_QUAD || opts->kernel == 3u || opts->kernel == 4u)) return MRT_ERR_INVALID; // 3, 4: retired ids
+	if (opts && ((opts->packet_wg != 0u && opts->packet_wg != 64u && opts->packet_wg != 256u) || opts->packet_cull > 2u || opts->tile_schedule > 1u || opts->kernel > MRT_KERNEL_PACKET_QUAD || opts->kernel == 3u || opts->kernel == 4u)) return MRT_ERR_INVALID; // 3, 4: retired ids
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || device_ordinal < 0 || device_ordinal >= n) return MRT_ERR_NO_DEVICE;
 	mrt_ctx *ctx = new (std::nothrow) mrt_ctx();
@@ -578,6 +620,10 @@ void mrt_destroy(mrt_ctx *ctx)
 	free_scene(ctx);
 	release(ctx->rays); release(ctx->hits); release(ctx->keys_in); release(ctx->keys_out);
 	release(ctx->idx_in); release(ctx->idx_out); release(ctx->sort_tmp); release(ctx->overflow);
+	if (ctx->sched.side) { (void)hipStreamSynchronize(ctx->sched.side); (void)hipStreamDestroy(ctx->sched.side); }
+	if (ctx->sched.traced) (void)hipEventDestroy(ctx->sched.traced);
+	for (int k = 0; k < 2; k++) { if (ctx->sched.ready[k]) (void)hipEventDestroy(ctx->sched.ready[k]); release(ctx->sched.cost[k]); release(ctx->sched.order[k]); }
+	release(ctx->sched.cost_sorted); release(ctx->sched.iota); release(ctx->sched.tmp);
 	if (ctx->d_counters) (void)hipFree(ctx->d_counters);
 	if (ctx->build_arena.ptr) (void)hipFree(ctx->build_arena.ptr);
 	if (ctx->h_auto) (void)hipHostFree(ctx->h_auto);
@@ -1026,6 +1072,130 @@ int mrt_collect(mrt_ctx *ctx, void *hits, uint64_t count)
 
 int mrt_has_pending(const mrt_ctx *ctx) { return ctx && ctx->pending ? 1 : 0; }
 
+// ---- frame-coherent tile schedule -------------------------------------------------------------------------------------
+// A grid cast ends with its slowest wave: packets differ 25-fold in cost (27 .. 667 rows at C3), and at renderer sizes
+// (1 - 2 M rays = 2 - 4 rounds of waves) the last round's long walks leave most of the chip idle: 1920x1080 ran at 3.8 Grays/s
+// against 9 at 4096^2.  Which tiles are expensive barely changes from one frame to the next, so every wave notes the
+// shader cycles its tile(s) took (TraceParams::tile_cost), a radix sort on a side stream turns that into a launch order,
+// longest first, and the next cast of the same grid (same size and rows; any camera: the order is only a permutation,
+// results never depend on it) launches in that order: the long walks start first and the short ones fill the gaps behind
+// them (longest-processing-time-first).  The first cast of a grid runs in the plain order.  mrt_options.tile_schedule = 1
+// turns it off.  For batches of 2^19 up to (not including) 2^24 rays: 1280x720 -17 %, 1920x1080 -18 %, 3840x2160 -13 %; at 4096^2
+// and above the gain is 2-4 % in kernel time and less than what the bookkeeping costs a blocking call; 640x360 measured 7 %
+// slower with it (too few tiles to reorder).  The order is renewed every kScheduleRenew-th frame, not every frame: which
+// tiles are expensive changes slowly, and a sort that runs beside the start of the next frame delays exactly the long walks
+// that frame launches first (1920x1080: 0.52 against 0.44 ms with a sort per frame).  A batch whose row width is found on the device
+// (mrt_cast with MRT_FLAG_COHERENT) is scheduled from the width the previous cast of the same size found.
+#ifndef MRT_SCHEDULE_MAX_LOG2
+#define MRT_SCHEDULE_MAX_LOG2 24
+#endif
+constexpr uint64_t kScheduleMinRays = 1ull << 19, kScheduleMaxRays = 1ull << MRT_SCHEDULE_MAX_LOG2; // 640x360 (2^17.8 rays) measured slower with it
+static bool schedule_applies(const mrt_ctx *ctx, const mrt::TraceParams &p)
+{
+	if (ctx->opts.tile_schedule == 1u || ctx->opts.count_visits) return false;
+	if ((p.lane_map != mrt::MAP_TILE8X8 && p.lane_map != mrt::MAP_AUTO) || p.count < kScheduleMinRays || p.count >= kScheduleMaxRays) return false;
+	return p.kernel == MRT_KERNEL_PACKET_ASM || (p.kernel == MRT_KERNEL_PACKET_DUAL && p.row_array != nullptr);
+}
+
+// Before the launch: the units of this grid, the newest finished order of the same grid, and -- on a measuring frame -- a
+// zeroed cost array.  Two generations of (cost, order): generation g is sorted on the side stream while later frames already
+// run in the order of generation g - 1; no frame waits for a running sort.
+constexpr uint32_t kScheduleRenew = 8;
+static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p)
+{
+	auto &s = ctx->sched;
+	const uint32_t th = 64u >> p.tile_w_log2;
+	const uint32_t tiles_y = (p.rows + th - 1u) / th;
+	const uint32_t unit = p.kernel == MRT_KERNEL_PACKET_DUAL ? 2u : 1u;
+	const uint64_t tiles = (uint64_t)p.tiles_x * tiles_y;
+	const uint32_t n_units = (uint32_t)((tiles + unit - 1u) / unit);
+	const bool same = s.grid_w == p.grid_w && s.grid_h == p.grid_h && s.y0 == p.y0 && s.rows == p.rows && s.unit == unit &&
+			s.n_units == n_units && s.tile_w_log2 == p.tile_w_log2;
+	int rc;
+	if (!s.side) {
+		HIP_TRY(ctx, hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
+		HIP_TRY(ctx, hipEventCreateWithFlags(&s.traced, hipEventDisableTiming));
+		for (int k = 0; k < 2; k++) HIP_TRY(ctx, hipEventCreateWithFlags(&s.ready[k], hipEventDisableTiming));
+	}
+	if (!same) {
+		HIP_TRY(ctx, hipStreamSynchronize(s.side)); // no sort of the old grid may still use the arrays
+		for (int k = 0; k < 2; k++)
+			if ((rc = ensure(ctx, s.cost[k], (size_t)n_units * 4)) || (rc = ensure(ctx, s.order[k], (size_t)n_units * 4))) return rc;
+		if ((rc = ensure(ctx, s.cost_sorted, (size_t)n_units * 4)) || (rc = ensure(ctx, s.iota, (size_t)n_units * 4))) return rc;
+		std::vector<uint32_t> iota(n_units);
+		for (uint32_t i = 0; i < n_units; i++) iota[i] = i;
+		HIP_TRY(ctx, hipMemcpyAsync(s.iota.ptr, iota.data(), (size_t)n_units * 4, hipMemcpyHostToDevice, ctx->stream));
+		HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); // (the host vector goes out of scope)
+		s.forget();
+		s.frame = 0; s.gen = 0;
+	}
+	s.grid_w = p.grid_w; s.grid_h = p.grid_h; s.y0 = p.y0; s.rows = p.rows; s.unit = unit; s.n_units = n_units; s.tile_w_log2 = p.tile_w_log2;
+	const uint32_t cur = s.gen & 1u, newest = cur ^ 1u;     // the slot the next generation goes to, the slot of the last one
+	// the order to launch in: the last generation's if its sort is done, else the one before (still intact in slot `cur`:
+	// that slot's ORDER array is rewritten only by the next sort, which runs after this frame's trace)
+	const uint32_t *order = nullptr;
+	if (s.have_order[newest] && hipEventQuery(s.ready[newest]) == hipSuccess) order = (const uint32_t *)s.order[newest].ptr;
+	(void)hipGetLastError(); // (hipErrorNotReady is not an error)
+	if (!order && s.have_order[cur] && hipEventQuery(s.ready[cur]) == hipSuccess) order = (const uint32_t *)s.order[cur].ptr;
+	(void)hipGetLastError();
+	// a measuring frame: the first two of a grid, then every kScheduleRenew-th -- if the slot's previous sort is done
+	s.measuring = (s.gen < 2u || s.frame % kScheduleRenew == 0u) && (!s.have_order[cur] || hipEventQuery(s.ready[cur]) == hipSuccess);
+	(void)hipGetLastError();
+	if (s.measuring) HIP_TRY(ctx, hipMemsetAsync(s.cost[cur].ptr, 0, (size_t)n_units * 4, ctx->stream));
+	p.tile_sched = order;
+	p.tile_cost = s.measuring ? (uint32_t *)s.cost[cur].ptr : nullptr;
+	p.tile_unit = unit; p.n_units = n_units;
+	return MRT_OK;
+}
+
+// After the launch (ev[4] recorded on the context's stream): on a measuring frame, sort its units by cost, descending, on the
+// side stream.
+static int schedule_sort(mrt_ctx *ctx)
+{
+	auto &s = ctx->sched;
+	s.frame++;
+	if (!s.measuring) return MRT_OK;
+	const uint32_t cur = s.gen & 1u;
+	HIP_TRY(ctx, hipEventRecord(s.traced, ctx->stream));
+	HIP_TRY(ctx, hipStreamWaitEvent(s.side, s.traced, 0));
+	size_t tmp_bytes = 0;
+	uint32_t *ki = (uint32_t *)s.cost[cur].ptr, *ko = (uint32_t *)s.cost_sorted.ptr, *vi = (uint32_t *)s.iota.ptr, *vo = (uint32_t *)s.order[cur].ptr;
+	HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(nullptr, tmp_bytes, ki, ko, vi, vo, (size_t)s.n_units, 0, 32, s.side));
+	int rc;
+	if (s.tmp.cap < tmp_bytes) { HIP_TRY(ctx, hipStreamSynchronize(s.side)); if ((rc = ensure(ctx, s.tmp, tmp_bytes))) return rc; }
+	HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(s.tmp.ptr, tmp_bytes, ki, ko, vi, vo, (size_t)s.n_units, 0, 32, s.side));
+	HIP_TRY(ctx, hipEventRecord(s.ready[cur], s.side));
+	s.have_order[cur] = true;
+	s.gen++;
+	return MRT_OK;
+}
+
+// The kernel of a mid-size grid cast, by measurement (mrt_ctx::GridTune).  Only for MRT_KERNEL_AUTO on flat scenes, blocking
+// casts (a timing is needed), grids the schedule applies to.
+static void tune_grid_kernel(mrt_ctx *ctx, mrt::TraceParams &p, int mode, uint32_t flags)
+{
+	auto &t = ctx->tune;
+	t.armed = false;
+	if (ctx->opts.kernel != MRT_KERNEL_AUTO || ctx->two_level || !ctx->d_rows || ctx->opts.count_visits || ctx->opts.tile_schedule == 1u) return;
+	if (p.lane_map != mrt::MAP_TILE8X8 || p.count < kScheduleMinRays || p.count >= kScheduleMaxRays) return;
+	if (p.kernel != MRT_KERNEL_PACKET_ASM && p.kernel != MRT_KERNEL_PACKET_DUAL) return;
+	const bool same = t.grid_w == p.grid_w && t.grid_h == p.grid_h && t.y0 == p.y0 && t.rows == p.rows && t.mode == mode;
+	if (!same) { t.grid_w = p.grid_w; t.grid_h = p.grid_h; t.y0 = p.y0; t.rows = p.rows; t.mode = mode; t.phase = 0; t.t_asm = t.t_dual = 0.0f; }
+	if (t.phase < 3) p.kernel = MRT_KERNEL_PACKET_ASM;
+	else if (t.phase < 6) p.kernel = MRT_KERNEL_PACKET_DUAL;
+	else p.kernel = t.t_dual < t.t_asm ? MRT_KERNEL_PACKET_DUAL : MRT_KERNEL_PACKET_ASM;
+	t.armed = t.phase < 6 && !(flags & MRT_FLAG_ASYNC);   // an ASYNC cast has no timing: the phase waits for a blocking one
+}
+static void tune_record(mrt_ctx *ctx)
+{
+	auto &t = ctx->tune;
+	if (!t.armed) return;
+	if (t.phase == 2) t.t_asm = ctx->stats.last_trace_ms;   // (the third frame of a kernel: launched in a measured order)
+	if (t.phase == 5) t.t_dual = ctx->stats.last_trace_ms;
+	t.phase++;
+	t.armed = false;
+}
+
 static int grid_params(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t grid_h, uint32_t y0, uint32_t y1, mrt::TraceParams &p)
 {
 	if (!cam || grid_w == 0 || grid_h == 0 || y0 > y1 || y1 > grid_h) return fail(ctx, MRT_ERR_INVALID, "bad grid");
@@ -1076,11 +1246,15 @@ int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t
 	p.out_fmt = out_format(ctx, flags, mode);
 	p.lane_map = ctx->opts.grid_tile == 1 ? mrt::MAP_LINEAR : mrt::MAP_TILE8X8;
 	p.kernel = pick_kernel(ctx, true, p.count);
+	tune_grid_kernel(ctx, p, mode, flags);
+	const bool scheduled = schedule_applies(ctx, p);
+	if (scheduled && (rc = schedule_grid(ctx, p))) return rc;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));
 	ctx->queued_kernel = p.kernel; std::snprintf(ctx->queued_variant, sizeof(ctx->queued_variant), "%s", mrt::last_trace_variant()); ctx->queued_alt_kernel = 0; ctx->queued_detect = false;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[4], ctx->stream));
+	if (scheduled && (rc = schedule_sort(ctx))) return rc;
 	if (flags & MRT_FLAG_ASYNC) { ctx->stats.rays_cast += p.count; ctx->stats.last_kernel = 0; return MRT_OK; }
 	if (!hits_dev) {
 		HIP_TRY(ctx, hipMemcpyAsync(hits, d_hits, p.count * hs, hipMemcpyDeviceToHost, ctx->stream));
@@ -1089,7 +1263,9 @@ int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
 	ctx->stats.last_kernel_launches = 1; ctx->stats.rays_cast += p.count;
 	ctx->stats.last_h2d_ms = ctx->stats.last_sort_ms = ctx->stats.last_d2h_ms = 0.0f;
-	return finish_timing(ctx, false, false, !hits_dev);
+	rc = finish_timing(ctx, false, false, !hits_dev);
+	if (rc == MRT_OK) tune_record(ctx);
+	return rc;
 }
 
 int mrt_cast_tiled(mrt_ctx *ctx, const mrt_ray32 *d_rays, mrt_hit32 *d_hits,

@@ -90,11 +90,18 @@ __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t 
 		grid_w = w; rows = p.auto_grid[1]; tiles_x = p.auto_grid[2];
 	}
 	if (lane_map == MAP_TILE8X8) {
-		const uint64_t tile = g >> 6;
+		uint64_t tile = g >> 6;
 		const uint32_t l = (uint32_t)g & 63u;
 		uint32_t tx, ty;
 		const uint32_t k = p.tile_w_log2; // tile is 2^k wide, 64 / 2^k high
 		const uint32_t tiles_y = (rows + (64u >> k) - 1u) >> (6u - k);
+		// the schedule of the previous frame: launch slot -> unit of tile_unit consecutive tiles.  Only if it is a schedule
+		// of THIS grid (a batch whose row width is found on the device, MAP_AUTO, was scheduled from the last cast's width)
+		if (p.tile_sched != nullptr && ((uint64_t)tiles_x * tiles_y + p.tile_unit - 1u) / p.tile_unit == p.n_units) {
+			const uint64_t slot = tile / p.tile_unit;
+			if (slot >= p.n_units) return false;
+			tile = (uint64_t)p.tile_sched[slot] * p.tile_unit + tile % p.tile_unit;
+		}
 		if (p.tile_order == 1u && (tiles_x & 15u) == 0u && (tiles_y & 15u) == 0u) {
 			// 16x16-tile super-tiles in row-major order, Z-order inside: the tiles in flight at
 			// any moment cover a compact image region, so they share deep BVH nodes in L2
@@ -124,6 +131,23 @@ __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t 
 	ray_idx = p.perm ? (uint64_t)p.perm[g] : g;
 	if (p.in_fmt == IN_GRID) { px = (uint32_t)(ray_idx % p.grid_w); py = (uint32_t)(ray_idx / p.grid_w); }
 	return true;
+}
+
+// The schedule unit a wave's first tile belongs to, and the note of what it cost (shader cycles), for the next frame's
+// longest-first launch order.  One lane per wave writes; a unit is written by exactly one wave.
+__device__ __forceinline__ void note_tile_cost(const TraceParams &p, uint64_t g_first, unsigned long long t_start)
+{
+	if (p.tile_cost == nullptr) return;
+	uint32_t rows = p.rows, tiles_x = p.tiles_x;
+	if (p.lane_map == MAP_AUTO) { if (p.auto_grid[0] == 0u) return; rows = p.auto_grid[1]; tiles_x = p.auto_grid[2]; }
+	else if (p.lane_map != MAP_TILE8X8) return;
+	const uint32_t k = p.tile_w_log2, tiles_y = (rows + (64u >> k) - 1u) >> (6u - k);
+	if (((uint64_t)tiles_x * tiles_y + p.tile_unit - 1u) / p.tile_unit != p.n_units) return; // not the grid the arrays were sized for
+	uint64_t unit = (g_first >> 6) / p.tile_unit;
+	if (unit >= p.n_units) return;
+	if (p.tile_sched != nullptr) unit = p.tile_sched[unit];
+	const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
+	p.tile_cost[unit] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
 }
 
 // Primary-ray grids.  MRT_CAMERA_DEBUG_GRID: RayTracerDebug::cast_debug_rays, src/godot/raytracer_debug.cpp:585-596
@@ -798,7 +822,7 @@ hipError_t launch_trace(const TraceParams &p_in, bool any_hit, bool count, hipSt
 			if (count) { if (any_hit) MRT_LAUNCH_ROWS(true, true, N, W, F); else MRT_LAUNCH_ROWS(false, true, N, W, F); } \
 			else { if (any_hit) MRT_LAUNCH_ROWS(true, false, N, W, F); else MRT_LAUNCH_ROWS(false, false, N, W, F); }   \
 		} while (0)
-		const bool cull = packets == 2u && p.rows_cull != 0u;
+		const bool cull = packets == 2u && (p.rows_cull == 1u || (p.rows_cull == 2u && p.in_fmt == IN_GRID));
 		if (packets == 2u && rows_wg == 64u) { if (cull) MRT_LAUNCH_ROWS_AC(2, 64, true); else MRT_LAUNCH_ROWS_AC(2, 64, false); }
 		else if (packets == 2u) { if (cull) MRT_LAUNCH_ROWS_AC(2, MRT_ROWS_WG_LARGE, true); else MRT_LAUNCH_ROWS_AC(2, MRT_ROWS_WG_LARGE, false); }
 		else MRT_LAUNCH_ROWS_AC(1, MRT_WG, false);

@@ -131,6 +131,12 @@ struct TraceParams {
 	uint32_t tile_w_log2;      // lane tile: 2^k wide, 64 / 2^k high
 	uint32_t tile_order;       // 0: tiles row-major, 1: Z-order inside 16x16-tile super-tiles, 2: 32x32, 3: column strips per XCD
 	uint32_t tile_group;       // tile_order 3: consecutive tiles per workgroup (set by launch_trace)
+	// Frame-coherent tile schedule of grid casts (api.hip, TileSchedule): launch slot u runs schedule unit tile_sched[u]
+	// (a unit = tile_unit consecutive tiles: 1, or 2 for the 128-ray walk) and leaves the shader cycles it took in
+	// tile_cost[unit]; the next cast of the same grid launches the units longest first.  Both may be null.
+	const uint32_t *tile_sched;
+	uint32_t *tile_cost;
+	uint32_t tile_unit, n_units;
 	uint32_t kernel;           // MRT_KERNEL_LANE / MRT_KERNEL_PACKET
 	uint32_t stack_depth;      // LDS stack entries per lane
 	uint32_t xcd_swizzle;      // 1: remap blockIdx so each XCD owns a contiguous band

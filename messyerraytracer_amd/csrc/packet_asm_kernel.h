@@ -236,6 +236,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_packet_asm_kernel(const TracePar
 		const uint32_t per = gridDim.x >> 3;
 		if (block < (per << 3)) block = (block & 7u) * per + (block >> 3);
 	}
+	const unsigned long long t_start = p.tile_cost != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
 	uint64_t ray_idx = 0; uint32_t px = 0, py = 0;
 	if (!lane_ray_index(p, block, ray_idx, px, py)) return; // exited lanes drop out of every mask
 	RayRegs r;
@@ -267,6 +268,8 @@ __global__ __launch_bounds__(MRT_WG) void trace_packet_asm_kernel(const TracePar
 	}
 
 	finish_ray(p, ray_idx, r, best_t, best_u, best_v, best_slot);
+	if (p.tile_cost != nullptr && (threadIdx.x & (MRT_WAVE - 1)) == 0u) // (lane 0 = the tile's first pixel: it has a ray whenever the tile has one)
+		note_tile_cost(p, ((uint64_t)block * MRT_WG + threadIdx.x) & ~63ull, t_start);
 
 	if (COUNT) packet_count(p, n_nodes, n_tris, 0u, best_slot != 0xFFFFFFFFu, live);
 }

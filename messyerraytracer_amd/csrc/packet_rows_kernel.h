@@ -881,7 +881,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS_WPE
 	uint32_t cnt_n = 0u, cnt_t = 0u; // COUNT: node rows / triangle rows fetched by this wave
 	uint32_t cnt_w = 0u;             // COUNT, one-packet loop: shader cycles between issuing a row fetch and having it
 	uint32_t sp_wide = 0u, sp_one = 0u; // COUNT: highest stack pointers seen (LDS byte addresses) by the 128-ray / the one-packet walk
-	const unsigned long long t_start = COUNT ? __builtin_amdgcn_s_memtime() : 0ull;
+	const unsigned long long t_start = (COUNT || p.tile_cost != nullptr) ? __builtin_amdgcn_s_memtime() : 0ull;
 	bool done_a = part_a == 0ull, done_b = part_b == 0ull;
 	if (PACKETS == 2 && !done_a && !done_b && oct_a == oct_b && oct_a != 8) {
 		// one walk for both groups: 32-byte stack entries over the wave's whole stack area, sentinel at its bottom;
@@ -932,6 +932,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS_WPE
 		if (PACKETS == 2 && lane_ray_index_g(p, h_a + MRT_WAVE, idx2, px2, py2)) finish_ray(p, idx2, rb, B.bt, B.bu, B.bv, slot_b);
 	}
 
+	if (p.tile_cost != nullptr && threadIdx.x % MRT_WAVE == 0u) note_tile_cost(p, (((uint64_t)block_s * (WG / MRT_WAVE) + wave_s) * PACKETS) * MRT_WAVE, t_start);
 	if (COUNT && lane == 0u && (p.count_mode != 2u || (blockIdx.x & 15u) == 0u)) { // the wave's clock: cycles in the row-fetch waits of the one-packet loop, cycles in all
 		atomicAdd(&p.counters[kCntFetchWaitCycles], (unsigned long long)cnt_w);
 		atomicAdd(&p.counters[kCntWaveCycles], __builtin_amdgcn_s_memtime() - t_start);

@@ -211,6 +211,33 @@ def test_packet_frustum_culling_skips_no_hit(built, cull):
     c.close()
 
 
+@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL])
+def test_frame_coherent_tile_schedule_changes_no_record(built, kernel):
+    """Grid casts of 2^15 .. 2^23 rays launch their tiles longest first by what each cost in the previous cast of the same grid
+    (mrt_options.tile_schedule, api.hip schedule_grid): any launch order gives the same records.  The same grid four times
+    (plain order, then three scheduled frames), another camera on the same grid (the old order is reused: still only a
+    permutation), a row block, a clipped grid, any-hit, tokens; and the same with the schedule off."""
+    v = synth.soup(20000, 0.25, 33)
+    scene, osc = capi.Scene(v), po.OracleScene(v)
+    for off in (0, 1):
+        c = capi.Context(0, kernel=kernel, tile_schedule=off)
+        scene.upload(c)
+        for (w, h) in ((512, 256), (333, 201)):
+            cam = capi.camera_look((0, 0, -12), (0, 0, 1), w, h, 50.0)
+            want = osc.trace(po.grid_rays((0, 0, -12), (0, 0, 1), w, h, 50.0))
+            for frame in range(4):
+                parity.assert_exact(c.cast_grid(cam, w, h), want, f"kernel {kernel} schedule off={off} {w}x{h} frame {frame}")
+            cam2 = capi.camera_look((3, 1, -11), (-0.2, 0, 1), w, h, 40.0)
+            parity.assert_exact(c.cast_grid(cam2, w, h), osc.trace(po.grid_rays((3, 1, -11), (-0.2, 0, 1), w, h, 40.0)), "another camera, the old order")
+            for frame in range(2):
+                parity.assert_exact(c.cast_grid(cam, w, h, y0=8, y1=h - 3), want[8 * w:(h - 3) * w], f"row block frame {frame}")
+                b = c.cast_grid(cam, w, h, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT)
+                assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
+                tok = c.cast_grid(cam, w, h, flags=capi.FLAG_TOKEN_OUT)
+                assert np.array_equal(tok != capi.TOKEN_MISS, want["prim_id"] >= 0)
+        c.close()
+
+
 @pytest.mark.parametrize("kernel", [capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_ROWS, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_QUAD])
 def test_partial_waves_and_clipped_tiles_on_every_packet_kernel(built, kernel):
     """Packets whose wave is not full: COHERENT batches of 1 .. 1000 rays (the last wave partial; at count = 1 lanes

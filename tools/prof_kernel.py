@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--count", type=int, default=0)
     ap.add_argument("--cull", type=int, default=0, help="mrt_options.packet_cull")
     ap.add_argument("--wg", type=int, default=0, help="mrt_options.packet_wg")
+    ap.add_argument("--entry", default="fused", choices=["fused", "cast"], help="mrt_cast_grid, or mrt_cast(COHERENT) on device-resident rays")
     a = ap.parse_args()
     cfg = synth.CONFIGS[a.config]
     w, h = cfg["grid"]
@@ -32,9 +33,16 @@ def main():
     c = capi.Context(0, kernel=a.kernel, count_visits=a.count, packet_cull=a.cull, packet_wg=a.wg)
     scene.upload(c)
     d_hits = c.device_alloc(w * h * 32)
+    d_rays = None
+    if a.entry == "cast":
+        d_rays = c.device_alloc(w * h * 32)
+        c.generate_grid(cam, w, h, 0, h, d_rays)
     ms = []
     for _ in range(a.iters):
-        c.cast_grid(cam, w, h, hits=d_hits, flags=capi.FLAG_HITS_ON_DEVICE)
+        if d_rays:
+            c.cast(d_rays, d_hits, count=w * h, flags=capi.FLAG_COHERENT | capi.FLAG_RAYS_ON_DEVICE | capi.FLAG_HITS_ON_DEVICE)
+        else:
+            c.cast_grid(cam, w, h, hits=d_hits, flags=capi.FLAG_HITS_ON_DEVICE)
         ms.append(c.stats()["last_trace_ms"])
     s = c.stats()
     print(json.dumps(dict(config=a.config, kernel=capi.kernel_name(s["last_kernel"]), median_ms=float(np.median(ms)), min_ms=float(min(ms)))))
