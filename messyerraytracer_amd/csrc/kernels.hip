@@ -133,21 +133,32 @@ __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t 
 	return true;
 }
 
-// The schedule unit a wave's first tile belongs to, and the note of what it cost (shader cycles), for the next frame's
-// longest-first launch order.  One lane per wave writes; a unit is written by exactly one wave.
-__device__ __forceinline__ void note_tile_cost(const TraceParams &p, uint64_t g_first, unsigned long long t_start)
+// What a wave's schedule unit cost (shader cycles, modulo 2^32), for the next frame's longest-first launch order.  The
+// start time is parked in the cost word itself (note_tile_start) and replaced by the difference at the end
+// (note_tile_cost): nothing stays in registers across the walk.  One lane per wave calls; a unit belongs to one wave.
+__device__ __forceinline__ bool tile_cost_word(const TraceParams &p, uint64_t g_first, uint32_t *&word)
 {
-	if (p.tile_cost == nullptr) return;
+	if (p.tile_cost == nullptr) return false;
 	uint32_t rows = p.rows, tiles_x = p.tiles_x;
-	if (p.lane_map == MAP_AUTO) { if (p.auto_grid[0] == 0u) return; rows = p.auto_grid[1]; tiles_x = p.auto_grid[2]; }
-	else if (p.lane_map != MAP_TILE8X8) return;
+	if (p.lane_map == MAP_AUTO) { if (p.auto_grid[0] == 0u) return false; rows = p.auto_grid[1]; tiles_x = p.auto_grid[2]; }
+	else if (p.lane_map != MAP_TILE8X8) return false;
 	const uint32_t k = p.tile_w_log2, tiles_y = (rows + (64u >> k) - 1u) >> (6u - k);
-	if (((uint64_t)tiles_x * tiles_y + p.tile_unit - 1u) / p.tile_unit != p.n_units) return; // not the grid the arrays were sized for
+	if (((uint64_t)tiles_x * tiles_y + p.tile_unit - 1u) / p.tile_unit != p.n_units) return false; // not the grid the arrays were sized for
 	uint64_t unit = (g_first >> 6) / p.tile_unit;
-	if (unit >= p.n_units) return;
+	if (unit >= p.n_units) return false;
 	if (p.tile_sched != nullptr) unit = p.tile_sched[unit];
-	const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_start;
-	p.tile_cost[unit] = dt > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)dt;
+	word = p.tile_cost + unit;
+	return true;
+}
+__device__ __forceinline__ void note_tile_start(const TraceParams &p, uint64_t g_first)
+{
+	uint32_t *w;
+	if (tile_cost_word(p, g_first, w)) *w = (uint32_t)__builtin_amdgcn_s_memtime();
+}
+__device__ __forceinline__ void note_tile_cost(const TraceParams &p, uint64_t g_first)
+{
+	uint32_t *w;
+	if (tile_cost_word(p, g_first, w)) { const uint32_t d = (uint32_t)__builtin_amdgcn_s_memtime() - *w; *w = d ? d : 1u; }
 }
 
 // Primary-ray grids.  MRT_CAMERA_DEBUG_GRID: RayTracerDebug::cast_debug_rays, src/godot/raytracer_debug.cpp:585-596

@@ -226,7 +226,7 @@ __device__ __forceinline__ void packet_traverse_asm(const TraceParams &p, const 
 }
 
 template <bool ANY_HIT, bool COUNT = false>
-__global__ __launch_bounds__(MRT_WG) void trace_packet_asm_kernel(const TraceParams p)
+__global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_num_sgpr(80))) void trace_packet_asm_kernel(const TraceParams p) // (80 scalar registers: 8 waves per SIMD; 81-96 would be 7)
 {
 	// 16-byte stack entries {ref, -, lane mask}; entry 0 holds the sentinel
 	__shared__ __attribute__((aligned(16))) uint32_t wave_stack[MRT_WG / MRT_WAVE][(MRT_PACKET_STACK + 1) * 4];
@@ -236,7 +236,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_packet_asm_kernel(const TracePar
 		const uint32_t per = gridDim.x >> 3;
 		if (block < (per << 3)) block = (block & 7u) * per + (block >> 3);
 	}
-	const unsigned long long t_start = p.tile_cost != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
+	if (p.tile_cost != nullptr && (threadIdx.x & (MRT_WAVE - 1)) == 0u) note_tile_start(p, ((uint64_t)block * MRT_WG + threadIdx.x) & ~63ull);
 	uint64_t ray_idx = 0; uint32_t px = 0, py = 0;
 	if (!lane_ray_index(p, block, ray_idx, px, py)) return; // exited lanes drop out of every mask
 	RayRegs r;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(MRT_WG) void trace_packet_asm_kernel(const TracePar
 
 	finish_ray(p, ray_idx, r, best_t, best_u, best_v, best_slot);
 	if (p.tile_cost != nullptr && (threadIdx.x & (MRT_WAVE - 1)) == 0u) // (lane 0 = the tile's first pixel: it has a ray whenever the tile has one)
-		note_tile_cost(p, ((uint64_t)block * MRT_WG + threadIdx.x) & ~63ull, t_start);
+		note_tile_cost(p, ((uint64_t)block * MRT_WG + threadIdx.x) & ~63ull);
 
 	if (COUNT) packet_count(p, n_nodes, n_tris, 0u, best_slot != 0xFFFFFFFFu, live);
 }

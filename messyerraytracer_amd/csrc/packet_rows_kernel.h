@@ -881,7 +881,10 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS_WPE
 	uint32_t cnt_n = 0u, cnt_t = 0u; // COUNT: node rows / triangle rows fetched by this wave
 	uint32_t cnt_w = 0u;             // COUNT, one-packet loop: shader cycles between issuing a row fetch and having it
 	uint32_t sp_wide = 0u, sp_one = 0u; // COUNT: highest stack pointers seen (LDS byte addresses) by the 128-ray / the one-packet walk
-	const unsigned long long t_start = (COUNT || p.tile_cost != nullptr) ? __builtin_amdgcn_s_memtime() : 0ull;
+	// the wave's start time waits in memory, not in registers (none to spare in the walk): in the cost array itself
+	// (note_tile_start / note_tile_cost), and for the counting builds in the unused words of the stack's sentinel entry
+	if (p.tile_cost != nullptr && lane == 0u) note_tile_start(p, g_a);
+	if (COUNT) *(volatile unsigned long long *)&stack_a[2] = __builtin_amdgcn_s_memtime();
 	bool done_a = part_a == 0ull, done_b = part_b == 0ull;
 	if (PACKETS == 2 && !done_a && !done_b && oct_a == oct_b && oct_a != 8) {
 		// one walk for both groups: 32-byte stack entries over the wave's whole stack area, sentinel at its bottom;
@@ -922,17 +925,18 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(MRT_ROWS_WPE
 		if (COUNT) { cnt_n += __builtin_amdgcn_readfirstlane(nn); cnt_t += __builtin_amdgcn_readfirstlane(nt); }
 	}
 
-	// The rays' indices again, from nothing the prologue computed (the wave from a scalar, the lane from the thread id):
-	// no index, pixel or validity flag stays live across the walk, where every vector register is spoken for.
+	// The rays' indices again, from nothing the prologue computed (the wave from a scalar, the lane from the exec-mask
+	// count): no index, pixel or validity flag stays live across the walk, where every vector register is spoken for
+	// (the compiler spilled 18 of them to scratch around the assembly block: 0.3 GB of writes per C3 launch).
 	{
 		const uint32_t lane2 = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
 		const uint64_t h_a = (((uint64_t)block_s * (WG / MRT_WAVE) + wave_s) * PACKETS) * MRT_WAVE + lane2;
 		uint64_t idx2 = 0; uint32_t px2 = 0, py2 = 0;
 		if (lane_ray_index_g(p, h_a, idx2, px2, py2)) finish_ray(p, idx2, ra, A.bt, A.bu, A.bv, slot_a);
 		if (PACKETS == 2 && lane_ray_index_g(p, h_a + MRT_WAVE, idx2, px2, py2)) finish_ray(p, idx2, rb, B.bt, B.bu, B.bv, slot_b);
+		if (p.tile_cost != nullptr && lane2 == 0u) note_tile_cost(p, h_a);
 	}
-
-	if (p.tile_cost != nullptr && threadIdx.x % MRT_WAVE == 0u) note_tile_cost(p, (((uint64_t)block_s * (WG / MRT_WAVE) + wave_s) * PACKETS) * MRT_WAVE, t_start);
+	const unsigned long long t_start = COUNT ? *(volatile unsigned long long *)&stack_a[2] : 0ull;
 	if (COUNT && lane == 0u && (p.count_mode != 2u || (blockIdx.x & 15u) == 0u)) { // the wave's clock: cycles in the row-fetch waits of the one-packet loop, cycles in all
 		atomicAdd(&p.counters[kCntFetchWaitCycles], (unsigned long long)cnt_w);
 		atomicAdd(&p.counters[kCntWaveCycles], __builtin_amdgcn_s_memtime() - t_start);

@@ -238,6 +238,31 @@ def test_frame_coherent_tile_schedule_changes_no_record(built, kernel):
         c.close()
 
 
+@pytest.mark.parametrize("wh", [(1280, 960), (1920, 1080)])
+def test_renderer_resolutions_on_the_c3_scene(built, wh):
+    """The reference's own workload size (1280x960: ROADMAP.md:175-181) and 1080p on the 1 M-triangle C3 scene: ten frames of
+    the same grid -- the measuring frames of both packet kernels, the frames launched in a measured tile order, the kernel
+    the library settles on -- every record of every frame against the oracle."""
+    w, h = wh
+    cfg = synth.CONFIGS["C3"]
+    verts = synth.scene_vertices(cfg)
+    c = capi.Context(0)
+    capi.Scene(verts).upload(c)
+    cam = capi.camera_look(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
+    want = po.OracleScene(verts).trace(po.grid_rays(cfg["origin"], cfg["forward"], w, h, cfg["fov"]), n_threads=16)
+    d_hits = c.device_alloc(w * h * 32)
+    seen = set()
+    got = np.zeros(w * h, dtype=T.HIT32)
+    for frame in range(10):
+        c.cast_grid(cam, w, h, hits=d_hits, flags=capi.FLAG_HITS_ON_DEVICE)
+        seen.add(c.last_kernel_variant())
+        c.d2h(got, d_hits)
+        parity.assert_exact(got, want, f"{w}x{h} frame {frame} ({c.last_kernel_variant()})")
+    assert len(seen) == 2, seen       # both packet kernels were measured on this grid
+    c.device_free(d_hits)
+    c.close()
+
+
 @pytest.mark.parametrize("kernel", [capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_ROWS, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_QUAD])
 def test_partial_waves_and_clipped_tiles_on_every_packet_kernel(built, kernel):
     """Packets whose wave is not full: COHERENT batches of 1 .. 1000 rays (the last wave partial; at count = 1 lanes
