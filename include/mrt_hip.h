@@ -459,6 +459,10 @@ int mrt_get_stats(mrt_ctx *ctx, mrt_stats *out);
  * reference counterpart (the reference prints its pipeline choice, gpu_ray_caster.cpp:654-671); bench.py uses it to
  * accept committed counter passes only for the very kernel a run used. */
 const char *mrt_last_kernel_variant(mrt_ctx *ctx);
+/* 1 if this build contains the kernel.  MRT_KERNEL_PACKET_QUAD (the four-wide packet walk: held to the oracle, not faster
+ * than the default) is compiled only into builds made with MRT_WITH_QUAD=1 (messyerraytracer_amd/build.py); mrt_create
+ * with it returns MRT_ERR_UNSUPPORTED otherwise. */
+int mrt_kernel_available(uint32_t kernel);
 int mrt_device_alloc(mrt_ctx *ctx, size_t bytes, void **d_ptr);
 int mrt_device_free(mrt_ctx *ctx, void *d_ptr);
 int mrt_memcpy_h2d(mrt_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);

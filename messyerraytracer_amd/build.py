@@ -37,10 +37,13 @@ def _stale(target: str, deps) -> bool:
 
 
 def build_lib(force: bool = False, verbose: bool = False) -> str:
+    """MRT_WITH_QUAD=1 in the environment also compiles the four-wide packet walk (packet_quad_kernel.h: an experiment kept
+    for the record, held to the oracle by the packet tests, slower than the default on every measured config)."""
     srcs = [os.path.join(CSRC, s) for s in SOURCES]
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     if force or _stale(LIB, deps):
-        cmd = [_hipcc()] + FLAGS + ["-shared"] + srcs + ["-o", LIB, "-pthread"]
+        extra = ["-DMRT_WITH_QUAD"] if os.environ.get("MRT_WITH_QUAD") == "1" else []
+        cmd = [_hipcc()] + FLAGS + extra + ["-shared"] + srcs + ["-o", LIB, "-pthread"]
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)

@@ -31,7 +31,7 @@ SYMBOLS = [
     "mrt_build_scene_device", "mrt_flatten_instances", "mrt_build_instanced_scene_device", "mrt_upload_two_level_scene", "mrt_update_instances", "mrt_two_level_prepare_host", "mrt_two_level_host_arrays", "mrt_two_level_free_host", "mrt_is_available", "mrt_scene_info", "mrt_cast", "mrt_submit", "mrt_collect", "mrt_has_pending",
     "mrt_camera_look", "mrt_camera_perspective", "mrt_camera_orthographic", "mrt_generate_grid", "mrt_cast_grid", "mrt_cast_tiled", "mrt_expand_tokens",
     "mrt_expand_grid_tokens", "mrt_token_bytes", "mrt_morton_keys",
-    "mrt_kernel_name", "mrt_struct_size", "mrt_get_stats", "mrt_last_kernel_variant", "mrt_device_alloc", "mrt_device_free", "mrt_memcpy_h2d", "mrt_memcpy_d2h",
+    "mrt_kernel_name", "mrt_struct_size", "mrt_get_stats", "mrt_last_kernel_variant", "mrt_kernel_available", "mrt_device_alloc", "mrt_device_free", "mrt_memcpy_h2d", "mrt_memcpy_d2h",
     "mrt_group_create", "mrt_group_destroy", "mrt_group_size", "mrt_group_context", "mrt_group_last_error", "mrt_group_row_block",
     "mrt_group_upload_scene", "mrt_group_upload_two_level_scene", "mrt_group_cast_grid",
 ]
@@ -207,6 +207,11 @@ def bvh2_load(path: str, n_tris: int):
     if rc:
         raise MrtError(rc, "mrt_bvh2_load")
     return nodes[:used.value].copy(), prim_idx, used.value
+
+
+def kernel_available(kernel_id: int) -> bool:
+    """Whether this build of libmrt_hip.so contains the kernel (KERNEL_PACKET_QUAD: only with MRT_WITH_QUAD=1)."""
+    return bool(load().mrt_kernel_available(C.c_uint32(kernel_id)))
 
 
 def kernel_name(kernel_id: int) -> str:

@@ -22,6 +22,7 @@
 namespace mrt {
 hipError_t launch_trace(const TraceParams &p, bool any_hit, bool count, hipStream_t stream);
 const char *last_trace_variant();
+bool quad_kernel_built();
 hipError_t launch_grid_rays(const TraceParams &p, mrt_ray32 *out, hipStream_t stream);
 hipError_t launch_build_rows4(const Dev4Node *nodes4, const TriHot *hot, const TriCold *cold, uint32_t n_nodes4, uint32_t n_tris,
 		void *rows, hipStream_t stream);
@@ -239,7 +240,7 @@ uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent, uint64_t count)
 int build_rows(mrt_ctx *ctx)
 {
 	// the 4-wide rows: when the 4-wide layout is resident and its worst-case stack fits the wave's 64 entries
-	const bool wanted4 = ctx->opts.kernel == MRT_KERNEL_PACKET_QUAD; // (AUTO never picks the four-wide walk: it is no faster)
+	const bool wanted4 = ctx->opts.kernel == MRT_KERNEL_PACKET_QUAD && mrt::quad_kernel_built(); // (AUTO never picks the four-wide walk: it is no faster)
 	const uint64_t n_units4 = (uint64_t)2u * ctx->n_nodes4 + ctx->n_tris;
 	if (wanted4 && ctx->d_nodes4 && ctx->n_nodes4 && ctx->stack4 <= 64u && n_units4 < mrt::kAsmNodeLimit) {
 		if (hipMalloc(&ctx->d_rows4, (size_t)n_units4 * 64u) != hipSuccess) { ctx->d_rows4 = nullptr; (void)hipGetLastError(); }
@@ -578,6 +579,14 @@ const char *mrt_kernel_name(uint32_t kernel)
 	}
 }
 
+// 1 if this build of the library contains the kernel (everything but MRT_KERNEL_PACKET_QUAD always; the four-wide packet
+// walk only in builds made with MRT_WITH_QUAD)
+int mrt_kernel_available(uint32_t kernel)
+{
+	if (kernel == MRT_KERNEL_PACKET_QUAD) return mrt::quad_kernel_built() ? 1 : 0;
+	return std::strcmp(mrt_kernel_name(kernel), "?") != 0 || kernel == MRT_KERNEL_AUTO ? 1 : 0;
+}
+
 const char *mrt_last_error(const mrt_ctx *ctx) { return ctx ? ctx->err : "null context"; }
 
 int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
@@ -585,6 +594,7 @@ int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
 	if (!out) return MRT_ERR_INVALID;
 	*out = nullptr;
 	if (opts && opts->struct_size != sizeof(mrt_options)) return MRT_ERR_INVALID;
+	if (opts && opts->kernel == MRT_KERNEL_PACKET_QUAD && !mrt::quad_kernel_built()) return MRT_ERR_UNSUPPORTED; // not in this build (MRT_WITH_QUAD)
 	if (opts && ((opts->packet_wg != 0u && opts->packet_wg != 64u && opts->packet_wg != 256u) || opts->packet_cull > 2u || opts->tile_schedule > 1u || opts->kernel > MRT_KERNEL_PACKET_QUAD || opts->kernel == 3u || opts->kernel == 4u)) return MRT_ERR_INVALID; // 3, 4: retired ids
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || device_ordinal < 0 || device_ordinal >= n) return MRT_ERR_NO_DEVICE;

@@ -420,7 +420,9 @@ __global__ __launch_bounds__(MRT_WG) void trace_lane_kernel(const TraceParams p)
 #include "packet_kernel.h"
 #include "packet_asm_kernel.h"
 #include "packet_rows_kernel.h"
+#ifdef MRT_WITH_QUAD   // the four-wide packet walk: measured, not faster; build.py MRT_WITH_QUAD=1 compiles it in
 #include "packet_quad_kernel.h"
+#endif
 #include "two_level_kernel.h"
 
 // ---- the unified row array of packet_rows_kernel.h ------------------------------------------------------------
@@ -768,6 +770,14 @@ hipError_t launch_origin_dir_keys(const void *rays, uint32_t in_fmt, uint64_t co
 }
 
 // ---- launch wrappers (called from api.hip) -------------------------------------------
+bool quad_kernel_built()
+{
+#ifdef MRT_WITH_QUAD
+	return true;
+#else
+	return false;
+#endif
+}
 // The instantiation the last launch_trace / launch_trace_persistent of this thread put on a stream, spelled as rocprofv3
 // prints it ("trace_packet_rows_kernel<false, false, 2, 64, true>"): mrt_last_kernel_variant, which bench.py uses to
 // accept committed counter passes only for the very kernel the run used.
@@ -809,6 +819,7 @@ hipError_t launch_trace(const TraceParams &p_in, bool any_hit, bool count, hipSt
 		note_variant("trace_two_level_kernel<%s>", MRT_B(any_hit));
 		return hipGetLastError();
 	}
+#ifdef MRT_WITH_QUAD
 	if (p.kernel == MRT_KERNEL_PACKET_QUAD && p.row_array4 != nullptr) {
 		// the 128-ray walk over 4-wide node rows: two packets per wave (half the waves)
 		const uint64_t rblocks = (threads + 2u * MRT_WG - 1) / (2u * MRT_WG);
@@ -821,6 +832,7 @@ hipError_t launch_trace(const TraceParams &p_in, bool any_hit, bool count, hipSt
 		note_variant("trace_packet_quad_kernel<%s, %s>", MRT_B(any_hit), MRT_B(count));
 		return hipGetLastError();
 	}
+#endif
 	if ((p.kernel == MRT_KERNEL_PACKET_DUAL || p.kernel == MRT_KERNEL_PACKET_ROWS) && p.row_array != nullptr) {
 		// the walk over the unified row array: one or two packets per wave (two: half the waves)
 		const uint32_t packets = p.kernel == MRT_KERNEL_PACKET_DUAL ? 2u : 1u;

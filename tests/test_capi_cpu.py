@@ -81,10 +81,19 @@ def test_options_are_validated_before_a_device_is_asked_for(built):
     assert capi.kernel_name(capi.KERNEL_PACKET_QUAD) == "trace_packet_quad_kernel"
     import torch
     if not torch.cuda.is_available():
-        for kw in (dict(kernel=capi.KERNEL_PACKET_QUAD), dict(packet_wg=64, packet_cull=2)):
+        for kw in (dict(kernel=capi.KERNEL_PACKET_DUAL), dict(packet_wg=64, packet_cull=2, tile_schedule=1)):
             with pytest.raises(capi.MrtError) as e:
                 capi.Context(0, **kw)
             assert e.value.status == capi.ERR_NO_DEVICE, kw
+    # the four-wide packet walk exists only in builds made with MRT_WITH_QUAD=1: otherwise the selection is refused as such
+    assert capi.kernel_available(capi.KERNEL_PACKET_DUAL) and capi.kernel_available(capi.KERNEL_AUTO) and not capi.kernel_available(3)
+    if not capi.kernel_available(capi.KERNEL_PACKET_QUAD):
+        with pytest.raises(capi.MrtError) as e:
+            capi.Context(0, kernel=capi.KERNEL_PACKET_QUAD)
+        assert e.value.status == capi.ERR_UNSUPPORTED
+    with pytest.raises(capi.MrtError) as e:
+        capi.Context(0, tile_schedule=2)
+    assert e.value.status == capi.ERR_INVALID
 
 
 @pytest.mark.parametrize("n,s,seed", [(1, 0.5, 1), (2, 0.5, 2), (3, 0.5, 3), (7, 0.5, 4), (1000, 0.5, 1), (60000, 0.15, 7)])

@@ -9,6 +9,8 @@ from oracle import pyoracle as po
 import parity
 
 pytestmark = pytest.mark.gpu
+# the four-wide packet walk is in builds made with MRT_WITH_QUAD=1 only (include/mrt_hip.h, mrt_kernel_available)
+QUAD = pytest.param(capi.KERNEL_PACKET_QUAD, marks=pytest.mark.skipif(not capi.kernel_available(capi.KERNEL_PACKET_QUAD), reason="built without MRT_WITH_QUAD"))
 
 
 def _rays(seed):
@@ -48,7 +50,7 @@ def test_device_built_tree_gives_the_oracles_hits(built, n_tris, scale, seed, pl
 
 
 @pytest.mark.parametrize("kernel", [capi.KERNEL_LANE, capi.KERNEL_PACKET,
-                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, capi.KERNEL_PACKET_QUAD, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
+                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, QUAD, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
                                     capi.KERNEL_LANE8_PERSISTENT])
 def test_every_kernel_walks_a_device_built_tree(built, kernel):
     """Kernels that want the 4-wide layout (absent for device-built trees) must fall back, not fault."""

@@ -14,6 +14,8 @@ from oracle import digests
 import parity
 
 pytestmark = pytest.mark.gpu
+# the four-wide packet walk is in builds made with MRT_WITH_QUAD=1 only (include/mrt_hip.h, mrt_kernel_available)
+QUAD = pytest.param(capi.KERNEL_PACKET_QUAD, marks=pytest.mark.skipif(not capi.kernel_available(capi.KERNEL_PACKET_QUAD), reason="built without MRT_WITH_QUAD"))
 
 
 def _golden(name):
@@ -263,7 +265,7 @@ def test_renderer_resolutions_on_the_c3_scene(built, wh):
     c.close()
 
 
-@pytest.mark.parametrize("kernel", [capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_ROWS, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_QUAD])
+@pytest.mark.parametrize("kernel", [capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_ROWS, capi.KERNEL_PACKET_DUAL, QUAD])
 def test_partial_waves_and_clipped_tiles_on_every_packet_kernel(built, kernel):
     """Packets whose wave is not full: COHERENT batches of 1 .. 1000 rays (the last wave partial; at count = 1 lanes
     1..63 have no ray) and grids whose right and bottom tiles are clipped, on the flat and the two-level packet walks.
@@ -432,7 +434,9 @@ def test_counting_variant_matches_oracle_counters(built):
         if kern != capi.KERNEL_PACKET_ASM:   # the row walks record their stack's high-water mark: never above what the BVH can need
             assert 0 < s["max_stack_depth"] <= c.scene_info()["stack_need"], (s["max_stack_depth"], c.scene_info())
         c.close()
-    # the four-wide packet walk: fewer rows than the two-wide walk fetches, the same hits
+    # the four-wide packet walk (builds with MRT_WITH_QUAD=1): fewer rows than the two-wide walk fetches, the same hits
+    if not capi.kernel_available(capi.KERNEL_PACKET_QUAD):
+        return
     c = capi.Context(0, kernel=capi.KERNEL_PACKET_QUAD, count_visits=True)
     scene.upload(c)
     parity.assert_exact(c.cast(rays, flags=capi.FLAG_COHERENT), want, "counting four-wide packet kernel")
@@ -520,7 +524,7 @@ def test_row_width_detection_for_coherent_batches(built):
 
 
 @pytest.mark.parametrize("kernel", [capi.KERNEL_LANE, capi.KERNEL_PACKET,
-                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, capi.KERNEL_PACKET_QUAD, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
+                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, QUAD, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
                                     capi.KERNEL_LANE8_PERSISTENT])
 def test_both_kernels_on_every_kind_of_batch(built, kernel):
     """Either kernel must give the oracle's answer for any batch, coherent or not:
@@ -589,7 +593,7 @@ def test_async_flag_queues_casts_back_to_back(ctx, soup1k):
 
 
 @pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET,
-                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, capi.KERNEL_PACKET_QUAD, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
+                                    capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, QUAD, capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT,
                                     capi.KERNEL_LANE8_PERSISTENT])
 def test_hit_tokens_expand_to_identical_records(built, kernel):
     """MRT_FLAG_TOKEN_OUT + mrt_expand_tokens == the records of a plain cast, byte for byte
@@ -871,7 +875,7 @@ def _tiled_wall(n=12, pitch=1.0):
 
 
 @pytest.mark.parametrize("pitch", [1.0, 0.3, 0.7])
-@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, capi.KERNEL_PACKET_QUAD,
+@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, QUAD,
                                     capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT, capi.KERNEL_LANE8_PERSISTENT])
 def test_rays_that_graze_box_faces(built, kernel, pitch):
     """Axis-parallel rays whose origins lie exactly on tile edges: the ray runs IN a face plane of leaf and
@@ -913,7 +917,7 @@ def test_rays_that_graze_box_faces(built, kernel, pitch):
     c.close()
 
 
-@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, capi.KERNEL_PACKET_QUAD,
+@pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_LANE, capi.KERNEL_PACKET, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL, capi.KERNEL_PACKET_ROWS, QUAD,
                                     capi.KERNEL_LANE_PERSISTENT, capi.KERNEL_LANE4_PERSISTENT, capi.KERNEL_LANE8_PERSISTENT])
 def test_non_finite_rays_do_not_disturb_their_neighbours(built, kernel):
     """The reference only asserts ray validity in debug builds (RT_ASSERT_VALID_RAY); a release caller can hand
