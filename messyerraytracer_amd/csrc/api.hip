@@ -1177,6 +1177,14 @@ static int schedule_sort(mrt_ctx *ctx)
 	HIP_TRY(ctx, hipEventRecord(s.ready[cur], s.side));
 	s.have_order[cur] = true;
 	s.gen++;
+	if (std::getenv("MRT_SCHED_DUMP")) { // diagnosis: what the schedule was made of (tools/bench_resolutions.py with MRT_SCHED_DUMP=1)
+		std::vector<uint32_t> c(s.n_units);
+		HIP_TRY(ctx, hipStreamSynchronize(s.side));
+		HIP_TRY(ctx, hipMemcpy(c.data(), s.cost_sorted.ptr, (size_t)s.n_units * 4, hipMemcpyDeviceToHost));
+		unsigned long long sum = 0; for (uint32_t v : c) sum += v;
+		std::fprintf(stderr, "[mrt schedule] %ux%u unit %u: %u units, cycles sum %llu, max %u, p99 %u, median %u, min %u\n", s.grid_w, s.rows, s.unit,
+				s.n_units, sum, c.empty() ? 0u : c[0], c.empty() ? 0u : c[s.n_units / 100], c.empty() ? 0u : c[s.n_units / 2], c.empty() ? 0u : c[s.n_units - 1]);
+	}
 	return MRT_OK;
 }
 

@@ -86,6 +86,13 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 	const float4 *nodes8 = reinterpret_cast<const float4 *>(p.nodes8);
 	const float4 *leaf_box = reinterpret_cast<const float4 *>(p.leaf_box);
 	const float4 *hot = reinterpret_cast<const float4 *>(p.tri_hot);
+	// Flat scenes that have the unified row array (packet_rows_kernel.h): triangles are read from its 64-byte rows
+	// {v0,id | e1,layers | e2,flags | normal} instead of the 48-byte TriHot rows, 3 of 8 of which straddle a 128-byte line
+	// (this kernel is bound by L2 requests per ray, DESIGN 4.3: 1.0 instead of 1.375 per triangle test), and the
+	// winner's normal comes from the same row.  Same values, same arithmetic.
+	const bool tri_rows = !TL && p.row_array != nullptr;
+	const float4 *tri_base = tri_rows ? reinterpret_cast<const float4 *>(p.row_array) + (size_t)p.n_nodes * 4u : hot;
+	const uint32_t tri_stride = tri_rows ? 4u : 3u;
 
 	// per-lane ray state
 	RayRegs r = {};
@@ -128,9 +135,10 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 			int32_t prim = -1; float nx = 0.0f, ny = 0.0f, nz = 0.0f; uint32_t layers = 0u;
 			if (TL) finish_two_level_ray(p, ray_idx, r, best_t, best_u, best_v, best_slot, best_id, best_inst);
 			else if (best_slot != 0xFFFFFFFFu) {
-				prim = (int32_t)p.tri_hot[best_slot].id;
-				layers = p.tri_hot[best_slot].layers;
-				const float4 nn = reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
+				const float4 *w3 = tri_base + (size_t)best_slot * tri_stride;
+				prim = (int32_t)__float_as_uint(w3[0].w);
+				layers = __float_as_uint(w3[1].w);
+				const float4 nn = tri_rows ? w3[3] : reinterpret_cast<const float4 *>(p.tri_cold)[best_slot];
 				nx = nn.x; ny = nn.y; nz = nn.z;
 			}
 			if (!TL) store_hit(p, ray_idx, r, best_t, prim, best_u, best_v, nx, ny, nz, layers, best_slot);
@@ -363,7 +371,7 @@ __global__ __launch_bounds__(MRT_WG) MRT_PERSIST_ATTR void trace_lane_persistent
 				const uint32_t leaf_first = slot;
 				bool last;
 				do {
-					const float4 *t3 = hot + (size_t)slot * 3u;
+					const float4 *t3 = tri_base + (size_t)slot * tri_stride;
 					const float4 q0 = t3[0], q1 = t3[1], q2 = t3[2];
 					last = (__float_as_uint(q2.w) & kLastInLeaf) != 0u;
 					if (TL || (__float_as_uint(q1.w) & p.query_mask) != 0u) { // TL: the mask was applied to the instance

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Runs one lane-kernel variant on config C4 (2^24 incoherent rays) a few times: the workload
 profiled by `rocprofv3 --pmc ... -- python3 tools/prof_c4.py [rounds] [kernel] [sort]`.
-kernel: lane | persistent | wide4 (default persistent); sort: 0 | 1 (default 0)."""
+kernel: lane | persistent | wide4 | wide8 | auto (default persistent; auto = the library's choice, which also has the row array); sort: 0 | 1 (default 0)."""
 import os
 import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,7 +10,7 @@ from messyerraytracer_amd import capi, synth  # noqa: E402
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 kernel = {"lane": capi.KERNEL_LANE, "persistent": capi.KERNEL_LANE_PERSISTENT,
-          "wide4": capi.KERNEL_LANE4_PERSISTENT, "wide8": capi.KERNEL_LANE8_PERSISTENT}[sys.argv[2] if len(sys.argv) > 2 else "persistent"]
+          "wide4": capi.KERNEL_LANE4_PERSISTENT, "wide8": capi.KERNEL_LANE8_PERSISTENT, "auto": capi.KERNEL_AUTO}[sys.argv[2] if len(sys.argv) > 2 else "persistent"]
 sort = len(sys.argv) > 3 and sys.argv[3] == "1"
 cfg = synth.CONFIGS["C4"]
 scene = capi.Scene(synth.scene_vertices(cfg))
