@@ -513,6 +513,20 @@ def main():
                     roof["limiter"] = "valu_issue"
         out["roofline"] = roof
         out["kernel_only_mrays"] = rank0_rays / (kernel_ms * 1e-3) / 1e6
+        if world == 1 and not rows_mode and a.mode != "fused":
+            # beside the headline entry (rays resident in HBM, the reference's cast_rays contract): the same grid through
+            # mrt_cast_grid, which generates the rays in the kernel -- the device-side form of cast_debug_rays(origin,
+            # forward, W, H, fov) (src/godot/raytracer_debug.cpp:539-634).  Outside the timed region; 12 blocking casts.
+            rec = torch.empty(n_rays * 32, dtype=torch.uint8, device=device)
+            fk, t1 = [], []
+            for i in range(12):
+                t0 = time.perf_counter()
+                ctx.cast_grid(cam, w, h, hits=rec, flags=capi.FLAG_HITS_ON_DEVICE)
+                t1.append(time.perf_counter() - t0)
+                fk.append(ctx.stats()["last_trace_ms"])
+            out["fused_grid"] = {"entry": "mrt_cast_grid", "kernel": ctx.last_kernel_variant(), "kernel_ms": float(np.median(fk[2:])),
+                                 "ms_per_step": float(np.median(t1[2:])) * 1e3, "mrays": n_rays / float(np.median(t1[2:])) / 1e6}
+            del rec
         if world == 1:
             # the reference's cast_rays(rays, results, count) contract: pageable host arrays in and out (PCIe inclusive)
             if not rows_mode and os.environ.get("MRT_BENCH_NO_HOST_PATH") != "1":
