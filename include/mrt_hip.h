@@ -320,10 +320,14 @@ enum {
 	MRT_BUILD_SAFE_HANDOFF   = 1u << 1, /* radix tree: the bottom-up pass hands boxes between threads with an
 	                                       acquire-release counter from the start (3x slower).  Every build verifies its
 	                                       tree afterwards and falls back to this form by itself if a hand-off was stale. */
-	MRT_BUILD_PLOC           = 1u << 3  /* parallel locally-ordered clustering on the sorted keys (merges by surface area
+	MRT_BUILD_PLOC           = 1u << 3, /* parallel locally-ordered clustering on the sorted keys (merges by surface area
 	                                       of the union, Meister and Bittner 2018) instead of the default radix tree over
 	                                       the key bits: 2.9 against 1.2 ms per million triangles; on the soup scenes of
 	                                       BASELINE.md the two trees trace alike (1.05 / 1.07 x the host SAH tree) */
+	MRT_BUILD_SAH            = 1u << 4  /* the binned-SAH tree of tinybvh::BVH::Build (tiny_bvh.h:2332-2466; mrt_bvh2_build on
+	                                       the host) built level by level on the device: the host builder's decisions on the
+	                                       same boxes, leaves of several triangles, rows in its depth-first order -- the tree
+	                                       RayScene::build would upload, without the host build */
 };
 int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris, uint32_t flags);
 

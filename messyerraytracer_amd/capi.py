@@ -19,7 +19,7 @@ ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_SCENE, ERR_PENDING, ERR_NOT_PENDING,
 MODE_NEAREST, MODE_ANY_HIT = 0, 1
 FLAG_COHERENT, FLAG_RAYS_ON_DEVICE, FLAG_HITS_ON_DEVICE, FLAG_HOST_LAYOUT, FLAG_BOOL_OUT, FLAG_FORCE_SORT, FLAG_TOKEN_OUT, FLAG_ASYNC = (1 << i for i in range(8))
 TOKEN_MISS = 0xFFFFFFFF
-BUILD_TRIS_ON_DEVICE, BUILD_SAFE_HANDOFF, BUILD_BLAS_ON_DEVICE, BUILD_PLOC = 1, 2, 4, 8
+BUILD_TRIS_ON_DEVICE, BUILD_SAFE_HANDOFF, BUILD_BLAS_ON_DEVICE, BUILD_PLOC, BUILD_SAH = 1, 2, 4, 8, 16
 KERNEL_AUTO, KERNEL_LANE, KERNEL_PACKET = 0, 1, 2   # (3 and 4: retired experiments, ids not reused)
 KERNEL_PACKET_ASM, KERNEL_LANE_PERSISTENT, KERNEL_LANE4_PERSISTENT, KERNEL_LANE8_PERSISTENT, KERNEL_PACKET_DUAL, KERNEL_PACKET_ROWS, KERNEL_PACKET_QUAD = 5, 6, 7, 8, 9, 10, 11
 KERNEL_TWO_LEVEL, KERNEL_TWO_LEVEL_PACKET, KERNEL_TWO_LEVEL_PERSISTENT, KERNEL_TWO_LEVEL_PERSISTENT8 = 100, 101, 102, 103  # reported only
@@ -293,13 +293,14 @@ class Context:
     def synchronize(self):
         self._chk(self.L.mrt_synchronize(self.h))
 
-    def build_scene_device(self, tris, n_tris=None, on_device=False, safe_handoff=False, ploc=False):
-        """LBVH built on the device from mrt_tri64 triangles (numpy array, or a device pointer with on_device)."""
+    def build_scene_device(self, tris, n_tris=None, on_device=False, safe_handoff=False, ploc=False, sah=False):
+        """BVH built on the device from mrt_tri64 triangles (numpy array, or a device pointer with on_device): the radix tree,
+        PLOC (ploc) or the host builder's binned-SAH tree (sah)."""
         if isinstance(tris, np.ndarray):
             tris = np.ascontiguousarray(tris)
             assert tris.dtype == T.TRI64
             n_tris = tris.shape[0]
-        flags = (BUILD_TRIS_ON_DEVICE if on_device else 0) | (BUILD_SAFE_HANDOFF if safe_handoff else 0) | (BUILD_PLOC if ploc else 0)
+        flags = (BUILD_TRIS_ON_DEVICE if on_device else 0) | (BUILD_SAFE_HANDOFF if safe_handoff else 0) | (BUILD_PLOC if ploc else 0) | (BUILD_SAH if sah else 0)
         self._chk(self.L.mrt_build_scene_device(self.h, _ptr(tris), n_tris, flags))
 
     def flatten_instances(self, verts9, instances, d_out, n_mesh_tris=None, on_device=False):

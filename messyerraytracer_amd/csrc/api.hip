@@ -636,6 +636,7 @@ void mrt_destroy(mrt_ctx *ctx)
 	release(ctx->sched.cost_sorted); release(ctx->sched.iota); release(ctx->sched.tmp);
 	if (ctx->d_counters) (void)hipFree(ctx->d_counters);
 	if (ctx->build_arena.ptr) (void)hipFree(ctx->build_arena.ptr);
+	if (ctx->build_arena.pinned) (void)hipHostFree(ctx->build_arena.pinned);
 	if (ctx->h_auto) (void)hipHostFree(ctx->h_auto);
 	if (ctx->h_small_in) (void)hipHostFree(ctx->h_small_in);
 	if (ctx->h_small_out) (void)hipHostFree(ctx->h_small_out);
@@ -743,7 +744,7 @@ int mrt_build_scene_device(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
 	mrt::DeviceBuildResult b;
 	const bool want4 = ctx->opts.kernel == MRT_KERNEL_LANE4_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_PACKET_QUAD || ctx->opts.kernel == MRT_KERNEL_AUTO;
 	const bool want8 = ctx->opts.kernel == MRT_KERNEL_LANE8_PERSISTENT || ctx->opts.kernel == MRT_KERNEL_AUTO;
-	rc = mrt::device_build_lbvh(d_tris, n_tris, want4, want8, (flags & MRT_BUILD_SAFE_HANDOFF) != 0, (flags & MRT_BUILD_PLOC) == 0, &ctx->build_arena, (void *)ctx->stream, &b,
+	rc = mrt::device_build_lbvh(d_tris, n_tris, want4, want8, (flags & MRT_BUILD_SAFE_HANDOFF) != 0, (flags & MRT_BUILD_SAH) ? 2 : (flags & MRT_BUILD_PLOC) ? 1 : 0, &ctx->build_arena, (void *)ctx->stream, &b,
 			ctx->err, sizeof(ctx->err));
 	if (staged) (void)hipFree(staged);
 	if (rc) return rc;
@@ -835,7 +836,7 @@ int mrt_build_instanced_scene_device(mrt_ctx *ctx, const float *verts9, uint32_t
 	mrt_tri64 *d_world = nullptr; uint32_t total = 0;
 	int rc = flatten_instances(ctx, verts9, n_mesh_tris, instances, n_instances, flags, nullptr, &d_world, &total);
 	if (rc) return rc;
-	rc = mrt_build_scene_device(ctx, d_world, total, MRT_BUILD_TRIS_ON_DEVICE | (flags & (MRT_BUILD_PLOC | MRT_BUILD_SAFE_HANDOFF)));
+	rc = mrt_build_scene_device(ctx, d_world, total, MRT_BUILD_TRIS_ON_DEVICE | (flags & (MRT_BUILD_PLOC | MRT_BUILD_SAH | MRT_BUILD_SAFE_HANDOFF)));
 	(void)hipFree(d_world);
 	return rc;
 }
@@ -860,7 +861,7 @@ static int build_blases_on_device(mrt_ctx *ctx, mrt::TwoLevelHost *h, const floa
 		hipError_t e = hipMemcpy(staged, tris.data(), (size_t)bl.n_tris * sizeof(mrt_tri64), hipMemcpyHostToDevice);
 		if (e != hipSuccess) { rc = fail(ctx, MRT_ERR_HIP, hipGetErrorString(e)); break; }
 		mrt::DeviceBuildResult b;
-		rc = mrt::device_build_lbvh(staged, bl.n_tris, false, h->wide8, false, true, &ctx->build_arena, (void *)ctx->stream, &b, ctx->err, sizeof(ctx->err));
+		rc = mrt::device_build_lbvh(staged, bl.n_tris, false, h->wide8, false, 0, &ctx->build_arena, (void *)ctx->stream, &b, ctx->err, sizeof(ctx->err));
 		if (rc) break;
 		e = mrt::launch_offset_refs(ctx->d_nodes + bl.root, b.nodes, b.n_nodes, bl.root, tri_base, (void *)ctx->stream);
 		if (h->wide8 && !(b.nodes8 && b.leaf_box)) h->wide8 = false; // a mesh whose boxes fit no grid: the scene goes without the 8-wide layout

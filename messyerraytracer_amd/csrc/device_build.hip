@@ -35,6 +35,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <vector>
 #include <string.h> // before rocprim: its texture_cache_iterator.hpp calls ::memset
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
@@ -252,8 +253,14 @@ __global__ __launch_bounds__(LBVH_WG) void lbvh_verify_kernel(const DevNode *nod
 		const uint32_t ref = side ? g.right_ref : g.left_ref;
 		const float *mn = side ? g.rmin : g.lmin, *mx = side ? g.rmax : g.lmax;
 		Box want;
-		if (ref & kLeafBit) want = tri_boxes[sorted_tri[ref & 0x7FFFFFFFu]];
-		else {
+		if (ref & kLeafBit) { // the union of the leaf's triangle boxes (one triangle per leaf in the radix and PLOC forms)
+			const uint32_t first = ref & 0x7FFFFFFFu, cnt = side ? g.right_count : g.left_count;
+			want = tri_boxes[sorted_tri[first]];
+			for (uint32_t j = 1; j < cnt; j++) {
+				const Box t = tri_boxes[sorted_tri[first + j]];
+				for (int k = 0; k < 3; k++) { want.mn[k] = fminf(want.mn[k], t.mn[k]); want.mx[k] = fmaxf(want.mx[k], t.mx[k]); }
+			}
+		} else {
 			const DevNode c = nodes[ref];
 			for (int k = 0; k < 3; k++) { want.mn[k] = fminf(c.lmin[k], c.rmin[k]); want.mx[k] = fmaxf(c.lmax[k], c.rmax[k]); }
 			const uint32_t d = node_depth[ref];
@@ -366,6 +373,276 @@ __global__ __launch_bounds__(LBVH_WG) void ploc_finish_kernel(const DevNode *sta
 	nodes[at] = g;
 	node_depth[at] = staged_depth[id];
 	if (at == 0u) *max_depth = staged_depth[id];
+}
+
+// ---- binned SAH (steps 2-5, the host builder's tree; MRT_BUILD_SAH) -----------------------------------------
+// tinybvh::BVH::Build (tiny_bvh.h:2332-2466; restated for the host in host/bvh_builder.cpp) as a level-synchronous
+// device build: the decisions — 8 bins per axis over the node's box by primitive-box centre, the sweep for the smallest
+// A_L N_L + A_R N_R, "split iff 1 + cost / A(node) < N", a side left empty = leaf — are the host's, operation for
+// operation (explicitly rounded fp32, no contraction), so the topology is the tree the host builder makes of the same
+// boxes.  What differs is how the work is laid out:
+//   * node_of[i] is the open node triangle i is in; per level every triangle still in an open node goes down the split
+//     its node got at the previous level and adds its box to the bins of the node it arrives in (3 axes x {min, max}
+//     x 3 + a count; max on an order-preserving encoding whose empty value is 0, so the bins of a level start as a
+//     memset).  21 global atomics per triangle and level made a million-triangle build 19 ms (25 G atomics/s is what
+//     the L2 gives); so the bins are accumulated in LDS: while at most 8 nodes are open every block keeps all of them
+//     (sah_bin_kernel), afterwards the active triangles are radix-sorted by the slot of their node each level
+//     (closed leaves drop off the end of the list), a block's 256 triangles then cover a run of consecutive slots,
+//     and it stores the bins of the slots it holds alone with plain coalesced stores, atomics only for the two it may
+//     share with its neighbours (sah_bin_sorted_kernel);
+//   * one thread per open node then sweeps its 24 bins, decides, and allocates the pair of children (an atomic counter:
+//     creation order = breadth first; a child with one triangle is a leaf at once);
+//   * when no node is open: subtree sizes bottom-up and preorder ranks top-down over the levels' id ranges give every
+//     split the row index the host's depth-first numbering gives it (scene_prep.cpp) and every leaf its first slot;
+//     a stable radix sort of (first slot, triangle) pairs is the leaf order.
+// Node ids are creation order and nondeterministic; ranks, rows and leaf order are not.
+struct SahNode { float mn[3]; uint32_t count; float mx[3]; uint32_t left; }; // left: id of the left child (right = left + 1); 0 = leaf / undecided
+#define SAH_BINS 8
+#define SAH_BIN_WORDS 8                         // ~ord(min x y z), ord(max x y z), count, unused
+#define SAH_SLOT_WORDS (3 * SAH_BINS * SAH_BIN_WORDS)
+#define SAH_LDS_SLOTS 8u
+#define SAH_NO_SLOT 0xFFFFFFFFu
+#define SAH_FAR 1e30f                           // BVH_FAR, tiny_bvh.h:140
+
+__device__ __forceinline__ int sah_bin(float bmn, float bmx, float nmn, float nmx)
+{
+	const float rpd = __fdiv_rn((float)SAH_BINS, __fsub_rn(nmx, nmn));
+	const float x = __fmul_rn(__fsub_rn(__fmul_rn(__fadd_rn(bmn, bmx), 0.5f), nmn), rpd);
+	const int bi = (x > -2147483648.0f && x < 2147483648.0f) ? (int)x : (int)0x80000000u; // cvttss2si
+	return bi > 0 ? (bi < SAH_BINS - 1 ? bi : SAH_BINS - 1) : 0;
+}
+
+// the top levels (at most SAH_LDS_SLOTS open nodes), triangle side: descend the split of the previous level, then bin
+// into the node arrived at (if it is open); every block keeps all open slots in LDS
+__global__ __launch_bounds__(LBVH_WG) void sah_bin_kernel(const Box *boxes, uint32_t n, uint32_t *node_of, const SahNode *nodes, const uint32_t *slot_of,
+		const uint32_t *split_of, uint32_t *bins)
+{
+	__shared__ uint32_t sh[SAH_LDS_SLOTS * SAH_SLOT_WORDS];
+	for (uint32_t t = threadIdx.x; t < SAH_LDS_SLOTS * SAH_SLOT_WORDS; t += LBVH_WG) sh[t] = 0u;
+	__syncthreads();
+	for (uint32_t i = blockIdx.x * LBVH_WG + threadIdx.x; i < n; i += gridDim.x * LBVH_WG) {
+		uint32_t nd = node_of[i];
+		SahNode N = nodes[nd];
+		const Box b = boxes[i];
+		if (N.left != 0u) {
+			const uint32_t sp = split_of[nd], axis = sp >> 8, pos = sp & 0xFFu;
+			nd = N.left + ((uint32_t)sah_bin(b.mn[axis], b.mx[axis], N.mn[axis], N.mx[axis]) > pos ? 1u : 0u);
+			node_of[i] = nd;
+			N = nodes[nd];
+		}
+		const uint32_t slot = slot_of[nd];
+		if (slot == SAH_NO_SLOT) continue;
+		uint32_t *base = sh + slot * SAH_SLOT_WORDS;
+		for (int a = 0; a < 3; a++) {
+			uint32_t *w = base + (a * SAH_BINS + sah_bin(b.mn[a], b.mx[a], N.mn[a], N.mx[a])) * SAH_BIN_WORDS;
+			for (int k = 0; k < 3; k++) { atomicMax(w + k, ~f2ord(b.mn[k])); atomicMax(w + 3 + k, f2ord(b.mx[k])); }
+			atomicAdd(w + 6, 1u);
+		}
+	}
+	__syncthreads();
+	for (uint32_t t = threadIdx.x; t < SAH_LDS_SLOTS * SAH_SLOT_WORDS; t += LBVH_WG) {
+		const uint32_t v = sh[t];
+		if (v == 0u) continue;
+		if ((t & (SAH_BIN_WORDS - 1u)) == 6u) atomicAdd(bins + t, v); else atomicMax(bins + t, v);
+	}
+}
+
+// the levels below, step 1: the active triangles (act[0 .. n_act), or all of them when act == nullptr) descend the split of the
+// previous level; key = the slot of the node arrived at (SAH_NO_SLOT: a leaf, the triangle leaves the list at the sort)
+__global__ __launch_bounds__(LBVH_WG) void sah_descend_kernel(const Box *boxes, const uint32_t *act, uint32_t n_act, uint32_t *node_of, const SahNode *nodes,
+		const uint32_t *slot_of, const uint32_t *split_of, uint32_t *keys, uint32_t *vals)
+{
+	const uint32_t j = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (j >= n_act) return;
+	const uint32_t i = act ? act[j] : j;
+	uint32_t nd = node_of[i];
+	const SahNode N = nodes[nd];
+	if (N.left != 0u) {
+		const uint32_t sp = split_of[nd], axis = sp >> 8, pos = sp & 0xFFu;
+		nd = N.left + ((uint32_t)sah_bin(boxes[i].mn[axis], boxes[i].mx[axis], N.mn[axis], N.mx[axis]) > pos ? 1u : 0u);
+		node_of[i] = nd;
+	}
+	keys[j] = slot_of[nd]; vals[j] = i;
+}
+
+// step 2 (after the sort by slot): a block's 256 list positions cover the consecutive slots first .. last; SAH_WIN of them at a time
+// are accumulated in LDS and written out -- plain stores for a slot this block holds alone, atomics for `first` / `last` when the
+// neighbouring block has triangles of the same node
+#define SAH_WIN 64u
+__global__ __launch_bounds__(LBVH_WG) void sah_bin_sorted_kernel(const Box *boxes, const uint32_t *act, const uint32_t *keys, uint32_t n_act, const uint32_t *node_of,
+		const SahNode *nodes, uint32_t *bins)
+{
+	__shared__ uint32_t sh[SAH_WIN * SAH_SLOT_WORDS];
+	const uint32_t p0 = blockIdx.x * LBVH_WG, p1 = p0 + LBVH_WG < n_act ? p0 + LBVH_WG : n_act, j = p0 + threadIdx.x;
+	const uint32_t first = keys[p0], last = keys[p1 - 1u];
+	const bool shared_first = p0 > 0u && keys[p0 - 1u] == first, shared_last = p1 < n_act && keys[p1] == last;
+	uint32_t slot = SAH_NO_SLOT;
+	Box b; SahNode N;
+	if (j < p1) { const uint32_t i = act[j]; slot = keys[j]; b = boxes[i]; N = nodes[node_of[i]]; }
+	for (uint32_t w0 = first; w0 <= last; w0 += SAH_WIN) {
+		const uint32_t nw = last - w0 + 1u < SAH_WIN ? last - w0 + 1u : SAH_WIN;
+		for (uint32_t t = threadIdx.x; t < nw * SAH_SLOT_WORDS; t += LBVH_WG) sh[t] = 0u;
+		__syncthreads();
+		if (slot != SAH_NO_SLOT && slot >= w0 && slot - w0 < nw) {
+			uint32_t *base = sh + (slot - w0) * SAH_SLOT_WORDS;
+			for (int a = 0; a < 3; a++) {
+				uint32_t *w = base + (a * SAH_BINS + sah_bin(b.mn[a], b.mx[a], N.mn[a], N.mx[a])) * SAH_BIN_WORDS;
+				for (int k = 0; k < 3; k++) { atomicMax(w + k, ~f2ord(b.mn[k])); atomicMax(w + 3 + k, f2ord(b.mx[k])); }
+				atomicAdd(w + 6, 1u);
+			}
+		}
+		__syncthreads();
+		for (uint32_t t = threadIdx.x; t < nw * SAH_SLOT_WORDS; t += LBVH_WG) {
+			const uint32_t s_ = w0 + t / SAH_SLOT_WORDS, v = sh[t];
+			uint32_t *dst = bins + (size_t)w0 * SAH_SLOT_WORDS + t;
+			if ((s_ == first && shared_first) || (s_ == last && shared_last)) {
+				if (v != 0u) { if ((t & (SAH_BIN_WORDS - 1u)) == 6u) atomicAdd(dst, v); else atomicMax(dst, v); }
+			} else *dst = v;
+		}
+		__syncthreads();
+	}
+}
+
+__device__ __forceinline__ float sah_half_area(const float mn[3], const float mx[3])
+{
+	const float e0 = __fsub_rn(mx[0], mn[0]), e1 = __fsub_rn(mx[1], mn[1]), e2 = __fsub_rn(mx[2], mn[2]);
+	return e0 < -SAH_FAR ? 0.0f : __fadd_rn(__fadd_rn(__fmul_rn(e0, e1), __fmul_rn(e1, e2)), __fmul_rn(e2, e0));
+}
+__device__ __forceinline__ void sah_bin_box(const uint32_t *w, float mn[3], float mx[3])
+{
+	for (int k = 0; k < 3; k++) {
+		mn[k] = w[k] == 0u ? SAH_FAR : ord2f(~w[k]);
+		mx[k] = w[3 + k] == 0u ? -SAH_FAR : ord2f(w[3 + k]);
+	}
+}
+
+// one level, node side.  ctr[0] = next free node id, ctr[1] = open nodes of the next level, ctr[2] = the triangles in them
+__global__ __launch_bounds__(64) void sah_split_kernel(SahNode *nodes, const uint32_t *open, uint32_t n_open, const uint32_t *bins, uint32_t *slot_of,
+		uint32_t *split_of, uint32_t *ctr, uint32_t *open_next, const uint32_t *bounds)
+{
+	// the block's 64 slots are staged through LDS (one coalesced read of 48 KB instead of 64 lanes striding 768 bytes apart: the
+	// widest level of a million-triangle build took 0.43 ms); odd stride: lane l's word w sits in bank (l + w) & 31
+	__shared__ uint32_t sh[64 * (SAH_SLOT_WORDS + 1)];
+	const uint32_t t0 = blockIdx.x * 64u, nt = n_open - t0 < 64u ? n_open - t0 : 64u;
+	for (uint32_t k = threadIdx.x; k < nt * SAH_SLOT_WORDS; k += 64u)
+		sh[(k / SAH_SLOT_WORDS) * (SAH_SLOT_WORDS + 1) + k % SAH_SLOT_WORDS] = bins[(size_t)t0 * SAH_SLOT_WORDS + k];
+	__syncthreads();
+	const uint32_t t = t0 + threadIdx.x;
+	if (t >= n_open) return;
+	const uint32_t id = open[t];
+	const SahNode N = nodes[id];
+	const uint32_t *slot = sh + threadIdx.x * (SAH_SLOT_WORDS + 1);
+	float ext[3];
+	for (int k = 0; k < 3; k++) ext[k] = __fsub_rn(N.mx[k], N.mn[k]);
+	const float rsav = __fdiv_rn(1.0f, __fadd_rn(__fadd_rn(__fmul_rn(ext[0], ext[1]), __fmul_rn(ext[1], ext[2])), __fmul_rn(ext[2], ext[0])));
+	float split_cost = SAH_FAR;
+	int best_axis = 0, best_pos = 0;
+	for (int a = 0; a < 3; a++) {
+		const float min_dim = __fmul_rn(__fsub_rn(ord2f(bounds[3 + a]), ord2f(bounds[a])), 1e-20f);
+		if (!(ext[a] > min_dim)) continue;
+		const uint32_t *ax = slot + a * SAH_BINS * SAH_BIN_WORDS;
+		float lmn[3] = { SAH_FAR, SAH_FAR, SAH_FAR }, lmx[3] = { -SAH_FAR, -SAH_FAR, -SAH_FAR };
+		float rmn[3] = { SAH_FAR, SAH_FAR, SAH_FAR }, rmx[3] = { -SAH_FAR, -SAH_FAR, -SAH_FAR };
+		float anl[SAH_BINS - 1], anr[SAH_BINS - 1];
+		uint32_t ln = 0, rn = 0;
+		for (int i = 0; i < SAH_BINS - 1; i++) {
+			float bmn[3], bmx[3];
+			sah_bin_box(ax + i * SAH_BIN_WORDS, bmn, bmx);
+			for (int k = 0; k < 3; k++) { lmn[k] = fminf(lmn[k], bmn[k]); lmx[k] = fmaxf(lmx[k], bmx[k]); }
+			sah_bin_box(ax + (SAH_BINS - 1 - i) * SAH_BIN_WORDS, bmn, bmx);
+			for (int k = 0; k < 3; k++) { rmn[k] = fminf(rmn[k], bmn[k]); rmx[k] = fmaxf(rmx[k], bmx[k]); }
+			ln += ax[i * SAH_BIN_WORDS + 6]; rn += ax[(SAH_BINS - 1 - i) * SAH_BIN_WORDS + 6];
+			anl[i] = ln == 0u ? SAH_FAR : __fmul_rn(sah_half_area(lmn, lmx), (float)ln);
+			anr[SAH_BINS - 2 - i] = rn == 0u ? SAH_FAR : __fmul_rn(sah_half_area(rmn, rmx), (float)rn);
+		}
+		for (int i = 0; i < SAH_BINS - 1; i++) {
+			const float c = __fadd_rn(anl[i], anr[i]);
+			if (c < split_cost) { split_cost = c; best_axis = a; best_pos = i; }
+		}
+	}
+	split_cost = __fadd_rn(1.0f, __fmul_rn(__fmul_rn(1.0f, rsav), split_cost));
+	uint32_t lc = 0;
+	const uint32_t *ax = slot + best_axis * SAH_BINS * SAH_BIN_WORDS;
+	for (int i = 0; i <= best_pos; i++) lc += ax[i * SAH_BIN_WORDS + 6];
+	const uint32_t rc = N.count - lc;
+	if (split_cost >= (float)N.count || lc == 0u || rc == 0u) { slot_of[id] = SAH_NO_SLOT; return; } // stays a leaf
+	SahNode L, R;
+	for (int k = 0; k < 3; k++) { L.mn[k] = R.mn[k] = SAH_FAR; L.mx[k] = R.mx[k] = -SAH_FAR; }
+	for (int i = 0; i < SAH_BINS; i++) {
+		float bmn[3], bmx[3];
+		sah_bin_box(ax + i * SAH_BIN_WORDS, bmn, bmx);
+		SahNode &D = i <= best_pos ? L : R;
+		for (int k = 0; k < 3; k++) { D.mn[k] = fminf(D.mn[k], bmn[k]); D.mx[k] = fmaxf(D.mx[k], bmx[k]); }
+	}
+	L.count = lc; R.count = rc; L.left = R.left = 0u;
+	const uint32_t pair = atomicAdd(&ctr[0], 2u);
+	nodes[pair] = L; nodes[pair + 1u] = R;
+	nodes[id].left = pair;
+	split_of[id] = ((uint32_t)best_axis << 8) | (uint32_t)best_pos;
+	for (uint32_t side = 0; side < 2u; side++) {
+		const uint32_t c = pair + side, cnt = side ? rc : lc;
+		if (cnt >= 2u) { const uint32_t s = atomicAdd(&ctr[1], 1u); open_next[s] = c; slot_of[c] = s; atomicAdd(&ctr[2], cnt); }
+		else slot_of[c] = SAH_NO_SLOT;
+	}
+}
+
+__global__ void sah_root_kernel(SahNode *nodes, uint32_t n, const uint32_t *bounds, uint32_t *slot_of, uint32_t *open, uint32_t *rank, uint32_t *first, uint32_t *ctr)
+{
+	ctr[0] = 1u;
+	SahNode r;
+	for (int k = 0; k < 3; k++) { r.mn[k] = ord2f(bounds[k]); r.mx[k] = ord2f(bounds[3 + k]); }
+	r.count = n; r.left = 0u;
+	nodes[0] = r; slot_of[0] = 0u; open[0] = 0u; rank[0] = 0u; first[0] = 0u;
+}
+
+// nodes [lo, hi) of one depth, deepest first: splits in the subtree, height
+__global__ __launch_bounds__(LBVH_WG) void sah_size_kernel(const SahNode *nodes, uint32_t lo, uint32_t hi, uint32_t *size, uint32_t *height)
+{
+	const uint32_t id = lo + blockIdx.x * LBVH_WG + threadIdx.x;
+	if (id >= hi) return;
+	const uint32_t l = nodes[id].left;
+	if (l == 0u) { size[id] = 0u; height[id] = 0u; return; }
+	size[id] = 1u + size[l] + size[l + 1u];
+	const uint32_t hl = height[l], hr = height[l + 1u];
+	height[id] = 1u + (hl > hr ? hl : hr);
+}
+
+// nodes [lo, hi) of one depth, root first: a split's row (its preorder rank), its children's ranks and first slots
+__global__ __launch_bounds__(LBVH_WG) void sah_emit_kernel(const SahNode *nodes, uint32_t lo, uint32_t hi, const uint32_t *size, const uint32_t *height,
+		uint32_t *rank, uint32_t *first, DevNode *rows, uint32_t *node_depth, uint32_t *max_depth)
+{
+	const uint32_t id = lo + blockIdx.x * LBVH_WG + threadIdx.x;
+	if (id >= hi) return;
+	const SahNode N = nodes[id];
+	if (N.left == 0u) return;
+	const uint32_t l = N.left, r = l + 1u, rk = rank[id], f = first[id];
+	const SahNode L = nodes[l], R = nodes[r];
+	rank[l] = rk + 1u; rank[r] = rk + 1u + size[l];
+	first[l] = f; first[r] = f + L.count;
+	DevNode g;
+	for (int k = 0; k < 3; k++) { g.lmin[k] = L.mn[k]; g.lmax[k] = L.mx[k]; g.rmin[k] = R.mn[k]; g.rmax[k] = R.mx[k]; }
+	g.left_ref = L.left ? rk + 1u : (kLeafBit | f); g.left_count = L.left ? 0u : L.count;
+	g.right_ref = R.left ? rk + 1u + size[l] : (kLeafBit | (f + L.count)); g.right_count = R.left ? 0u : R.count;
+	rows[rk] = g;
+	node_depth[rk] = height[id];
+	if (id == 0u) *max_depth = height[id];
+}
+
+// leaf order: key = first slot of the triangle's leaf.  wrap_lc != 0: the root stayed a leaf and is wrapped in a row whose
+// two children are its halves (scene_prep.cpp does the same to a host tree): the first wrap_lc triangles, and the rest
+__global__ __launch_bounds__(LBVH_WG) void sah_keys_kernel(const uint32_t *node_of, const uint32_t *first, uint32_t n, uint32_t wrap_lc, uint32_t *keys, uint32_t *index)
+{
+	const uint32_t i = blockIdx.x * LBVH_WG + threadIdx.x;
+	if (i >= n) return;
+	keys[i] = wrap_lc ? (i < wrap_lc ? 0u : wrap_lc) : first[node_of[i]];
+	index[i] = i;
+}
+__global__ void sah_wrap_kernel(const uint32_t *bounds, uint32_t n, uint32_t lc, DevNode *rows, uint32_t *node_depth, uint32_t *max_depth)
+{
+	DevNode g;
+	for (int k = 0; k < 3; k++) { g.lmin[k] = g.rmin[k] = ord2f(bounds[k]); g.lmax[k] = g.rmax[k] = ord2f(bounds[3 + k]); }
+	g.left_ref = kLeafBit; g.left_count = lc; g.right_ref = kLeafBit | lc; g.right_count = n - lc;
+	rows[0] = g; node_depth[0] = 1u; *max_depth = 1u;
 }
 
 // 5b. 4-wide collapse for the incoherent-ray kernel (one 128-byte line per step): the rule of
@@ -484,15 +761,18 @@ __global__ __launch_bounds__(LBVH_WG) void lbvh_collapse8_kernel(const DevNode *
 }
 
 // 6. triangle rows in leaf order (sorted position = slot); every leaf holds one triangle
-__global__ __launch_bounds__(LBVH_WG) void lbvh_leaves_kernel(const mrt_tri64 *tris, uint32_t n, const uint32_t *sorted_tri, TriHot *hot, TriCold *cold)
+//    (leaf_key == nullptr), or the slots with one key form a leaf (the binned-SAH form: key = the leaf's first slot)
+__global__ __launch_bounds__(LBVH_WG) void lbvh_leaves_kernel(const mrt_tri64 *tris, uint32_t n, const uint32_t *sorted_tri, const uint32_t *leaf_key,
+		TriHot *hot, TriCold *cold)
 {
 	const uint32_t slot = blockIdx.x * LBVH_WG + threadIdx.x;
 	if (slot >= n) return;
+	const bool last = leaf_key == nullptr || slot + 1u == n || leaf_key[slot + 1u] != leaf_key[slot];
 	const float4 *t = reinterpret_cast<const float4 *>(tris + sorted_tri[slot]);
 	const float4 a = t[0], b = t[1], c = t[2], d = t[3];
 	float4 *h = reinterpret_cast<float4 *>(hot + slot);
 	h[0] = a; h[1] = b;
-	float4 c2 = c; c2.w = __uint_as_float(kLastInLeaf);
+	float4 c2 = c; c2.w = __uint_as_float(last ? kLastInLeaf : 0u);
 	h[2] = c2;
 	float4 nn = d; nn.w = 0.0f;
 	reinterpret_cast<float4 *>(cold)[slot] = nn;
@@ -598,7 +878,7 @@ hipError_t launch_flatten_instances(const float *d_verts9, const mrt_instance *d
 // Builds nodes / hot / cold (and nodes4 / nodes8 if wanted; hipMalloc'ed, owned by the caller on success) for
 // the n >= 2 triangles at d_tris (device).  depth = stack entries a traversal can need (incl. the sentinel).
 // Temporaries are carved from *arena (grown here if it is too small; owned by the caller, kept between builds).
-int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want8, bool safe_handoff, bool fast_lbvh, BuildArena *arena, void *stream_,
+int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want8, bool safe_handoff, int form, BuildArena *arena, void *stream_,
 		DeviceBuildResult *out, char *err, size_t err_len)
 {
 	hipStream_t stream = (hipStream_t)stream_;
@@ -629,7 +909,15 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 	const size_t o_cbox0 = reserve(nn * sizeof(Box)), o_cbox1 = reserve(nn * sizeof(Box)), o_cref0 = reserve(nn * 4), o_cref1 = reserve(nn * 4),
 			o_cdep0 = reserve(nn * 4), o_cdep1 = reserve(nn * 4), o_nn = reserve(nn * 4), o_flags = reserve(nn * 8), o_pos = reserve(nn * 8),
 			o_staged = reserve(nn * sizeof(DevNode)), o_sdepth = reserve(nn * 4);
+	const size_t ploc_end = need;
+	need = o_left;
+	// binned-SAH form: 2 n nodes with their side arrays, the open lists, node_of, the bins of the widest level (<= n / 2 open nodes)
+	const size_t o_snodes = reserve(2 * nn * sizeof(SahNode)), o_slot = reserve(2 * nn * 4), o_split = reserve(2 * nn * 4), o_size = reserve(2 * nn * 4),
+			o_height = reserve(2 * nn * 4), o_rank = reserve(2 * nn * 4), o_first = reserve(2 * nn * 4), o_open0 = reserve(nn * 4), o_open1 = reserve(nn * 4),
+			o_node_of = reserve(nn * 4), o_bins = reserve((nn / 2 + SAH_LDS_SLOTS) * SAH_SLOT_WORDS * 4);
+	if (form != 2) need = o_left; // (the bins are 384 bytes per triangle: only a build that asks for this form pays for them)
 	if (need < lbvh_end) need = lbvh_end;
+	if (need < ploc_end) need = ploc_end;
 	if (arena->cap < need) {
 		if (arena->ptr) { DB_TRY(hipStreamSynchronize(stream)); (void)hipFree(arena->ptr); arena->ptr = nullptr; arena->cap = 0; }
 		if (hipMalloc(&arena->ptr, need) != hipSuccess) { arena->ptr = nullptr; std::snprintf(err, err_len, "device build: out of device memory"); return MRT_ERR_OOM; }
@@ -653,11 +941,92 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 	DB_TRY(hipMemcpyAsync(scal, init, sizeof(init), hipMemcpyHostToDevice, stream));
 	hipLaunchKernelGGL(lbvh_bounds_kernel, dim3(blocks < LBVH_BOUNDS_BLOCKS ? blocks : LBVH_BOUNDS_BLOCKS), dim3(LBVH_WG), 0, stream,
 			d_tris, n, boxes, scal);
-	hipLaunchKernelGGL(lbvh_keys_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, boxes, n, scal, keys_a, idx_a);
-	DB_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys_a, keys_b, idx_a, idx_b, nn, 0, 63, stream));
-	hipLaunchKernelGGL(lbvh_leaves_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, d_tris, n, idx_b, hot, cold);
+	if (form != 2) {
+		hipLaunchKernelGGL(lbvh_keys_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, boxes, n, scal, keys_a, idx_a);
+		DB_TRY(rocprim::radix_sort_pairs(sort_tmp, sort_bytes, keys_a, keys_b, idx_a, idx_b, nn, 0, 63, stream));
+	}
+	if (form != 2) hipLaunchKernelGGL(lbvh_leaves_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, d_tris, n, idx_b, (const uint32_t *)nullptr, hot, cold);
 	uint32_t h[16];
-	if (!fast_lbvh) {
+	uint32_t n_rows = n - 1u;
+	if (form == 2) {
+		// ---- binned SAH, level by level ----
+		SahNode *snodes = (SahNode *)(A + o_snodes);
+		uint32_t *slot_of = (uint32_t *)(A + o_slot), *split_of = (uint32_t *)(A + o_split), *size = (uint32_t *)(A + o_size), *height = (uint32_t *)(A + o_height),
+				*rank = (uint32_t *)(A + o_rank), *first = (uint32_t *)(A + o_first), *node_of = (uint32_t *)(A + o_node_of), *bins = (uint32_t *)(A + o_bins);
+		uint32_t *open[2] = { (uint32_t *)(A + o_open0), (uint32_t *)(A + o_open1) };
+		if (!arena->pinned) DB_TRY(hipHostMalloc((void **)&arena->pinned, 64));
+		uint32_t *ctr = scal + 12; // [12] next free node id, [13] open nodes of the next level, [14] the triangles in them
+		// the list of active triangles and its sort keys, in / out of the sort: the halves of the two Morton-key arrays (unused by this form)
+		uint32_t *key_in = (uint32_t *)keys_a, *val_in = key_in + nn, *key_out = (uint32_t *)keys_b, *val_out = key_out + nn;
+		DB_TRY(hipMemsetAsync(node_of, 0, nn * 4, stream));
+		hipLaunchKernelGGL(sah_root_kernel, dim3(1), dim3(1), 0, stream, snodes, n, scal, slot_of, open[0], rank, first, ctr);
+		std::vector<uint32_t> level_lo; // ids of the nodes of depth d: [level_lo[d], level_lo[d + 1])
+		level_lo.push_back(0u); level_lo.push_back(1u);
+		uint32_t n_open = 1u, n_ids = 1u, n_list = n, n_act = n; // n_list: triangles on the list; n_act: those in this level's open nodes
+		const uint32_t *act = nullptr;                          // nullptr: the list is every triangle, in index order
+		int cur = 0;
+		while (n_open > 0u) {
+			if (level_lo.size() > 4096u) { std::snprintf(err, err_len, "device build: the SAH subdivision did not end"); cleanup(); return MRT_ERR_HIP; }
+			if ((size_t)n_open > nn / 2 + SAH_LDS_SLOTS || n_act > n_list) { std::snprintf(err, err_len, "device build: inconsistent SAH level (%u open nodes, %u of %u triangles)", n_open, n_act, n_list); cleanup(); return MRT_ERR_HIP; }
+			DB_TRY(hipMemsetAsync(ctr + 1, 0, 8, stream)); // (ctr[0], the next free id, runs on from level to level)
+			DB_TRY(hipMemsetAsync(bins, 0, (size_t)(n_open < SAH_LDS_SLOTS ? SAH_LDS_SLOTS : n_open) * SAH_SLOT_WORDS * 4, stream));
+			if (act == nullptr && n_open <= SAH_LDS_SLOTS)
+				hipLaunchKernelGGL(sah_bin_kernel, dim3(blocks < 1024u ? blocks : 1024u), dim3(LBVH_WG), 0, stream, boxes, n, node_of, snodes, slot_of, split_of, bins);
+			else {
+				hipLaunchKernelGGL(sah_descend_kernel, dim3((n_list + LBVH_WG - 1) / LBVH_WG), dim3(LBVH_WG), 0, stream, boxes, act, n_list, node_of, snodes, slot_of, split_of, key_in, val_in);
+				// the closed triangles' key is all ones: above every slot in the low `bits` bits too
+				const unsigned bits = 32u - (unsigned)__builtin_clz(n_open);
+				size_t sort32 = 0;
+				DB_TRY(rocprim::radix_sort_pairs(nullptr, sort32, key_in, key_out, val_in, val_out, (size_t)n_list, 0, bits, stream));
+				if (sort32 > (sort_bytes > scan_bytes ? sort_bytes : scan_bytes)) { std::snprintf(err, err_len, "device build: sort workspace"); cleanup(); return MRT_ERR_HIP; }
+				DB_TRY(rocprim::radix_sort_pairs(sort_tmp, sort32, key_in, key_out, val_in, val_out, (size_t)n_list, 0, bits, stream));
+				act = val_out; n_list = n_act;
+				hipLaunchKernelGGL(sah_bin_sorted_kernel, dim3((n_list + LBVH_WG - 1) / LBVH_WG), dim3(LBVH_WG), 0, stream, boxes, act, key_out, n_list, node_of, snodes, bins);
+			}
+			hipLaunchKernelGGL(sah_split_kernel, dim3((n_open + 63u) / 64u), dim3(64), 0, stream, snodes, open[cur], n_open, bins, slot_of, split_of, ctr, open[cur ^ 1], scal);
+			uint32_t *got = arena->pinned;
+			DB_TRY(hipMemcpyAsync(got, ctr, 12, hipMemcpyDeviceToHost, stream));
+			DB_TRY(hipStreamSynchronize(stream));
+			if (got[0] < n_ids || got[0] > 2u * n - 1u) { std::snprintf(err, err_len, "device build: the SAH subdivision made %u nodes for %u triangles", got[0], n); cleanup(); return MRT_ERR_HIP; }
+			if (got[0] > n_ids) level_lo.push_back(got[0]);
+			n_ids = got[0]; n_open = got[1]; n_act = got[2];
+			cur ^= 1;
+		}
+		// the triangles of the nodes split last still sit in their parent: one more descent
+		hipLaunchKernelGGL(sah_descend_kernel, dim3((n_list + LBVH_WG - 1) / LBVH_WG), dim3(LBVH_WG), 0, stream, boxes, act, n_list, node_of, snodes, slot_of, split_of, key_in, val_in);
+		const uint32_t depths = (uint32_t)level_lo.size() - 1u;
+		uint32_t wrap_lc = 0u;
+		if (n_ids == 1u) { // the root stayed a leaf (coincident triangles): one row, its halves
+			wrap_lc = (n + 1u) / 2u; n_rows = 1u;
+			hipLaunchKernelGGL(sah_wrap_kernel, dim3(1), dim3(1), 0, stream, scal, n, wrap_lc, nodes, node_depth, scal + 6);
+		} else {
+			n_rows = (n_ids - 1u) / 2u;
+			for (uint32_t d = depths; d-- > 0u;) {
+				const uint32_t lo = level_lo[d], hi = level_lo[d + 1];
+				hipLaunchKernelGGL(sah_size_kernel, dim3((hi - lo + LBVH_WG - 1) / LBVH_WG), dim3(LBVH_WG), 0, stream, snodes, lo, hi, size, height);
+			}
+			for (uint32_t d = 0; d < depths; d++) {
+				const uint32_t lo = level_lo[d], hi = level_lo[d + 1];
+				hipLaunchKernelGGL(sah_emit_kernel, dim3((hi - lo + LBVH_WG - 1) / LBVH_WG), dim3(LBVH_WG), 0, stream, snodes, lo, hi, size, height, rank, first,
+						nodes, node_depth, scal + 6);
+			}
+		}
+		uint32_t *key32_a = (uint32_t *)keys_a, *key32_b = (uint32_t *)keys_b;
+		hipLaunchKernelGGL(sah_keys_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, node_of, first, n, wrap_lc, key32_a, idx_a);
+		size_t sort32 = 0;
+		DB_TRY(rocprim::radix_sort_pairs(nullptr, sort32, key32_a, key32_b, idx_a, idx_b, nn, 0, 32, stream));
+		if (sort32 > (sort_bytes > scan_bytes ? sort_bytes : scan_bytes)) { std::snprintf(err, err_len, "device build: sort workspace"); cleanup(); return MRT_ERR_HIP; }
+		DB_TRY(rocprim::radix_sort_pairs(sort_tmp, sort32, key32_a, key32_b, idx_a, idx_b, nn, 0, 32, stream));
+		hipLaunchKernelGGL(lbvh_leaves_kernel, dim3(blocks), dim3(LBVH_WG), 0, stream, d_tris, n, idx_b, (const uint32_t *)key32_b, hot, cold);
+		const uint32_t rb = (n_rows + LBVH_WG - 1) / LBVH_WG;
+		if (!wrap_lc) hipLaunchKernelGGL(lbvh_verify_kernel, dim3(rb), dim3(LBVH_WG), 0, stream, nodes, n_rows, boxes, idx_b, node_depth, scal + 6, scal + 8);
+		if (want4) hipLaunchKernelGGL(lbvh_collapse4_kernel, dim3(rb), dim3(LBVH_WG), 0, stream, nodes, n_rows, nodes4);
+		if (want8) hipLaunchKernelGGL(lbvh_collapse8_kernel, dim3(rb), dim3(LBVH_WG), 0, stream, nodes, n_rows, nodes8, leaf_box, scal + 7);
+		DB_TRY(hipGetLastError());
+		DB_TRY(hipMemcpyAsync(h, scal, sizeof(h), hipMemcpyDeviceToHost, stream));
+		DB_TRY(hipStreamSynchronize(stream));
+		if (h[8] != 0u) { std::snprintf(err, err_len, "device build: the tree failed its verification pass (%u nodes)", h[8]); cleanup(); return MRT_ERR_HIP; }
+	} else if (form == 1) {
 		// ---- PLOC: rounds of nearest neighbour / flags / prefix sum / merge on the line of clusters ----
 		Box *cbox[2] = { (Box *)(A + o_cbox0), (Box *)(A + o_cbox1) };
 		uint32_t *cref[2] = { (uint32_t *)(A + o_cref0), (uint32_t *)(A + o_cref1) }, *cdep[2] = { (uint32_t *)(A + o_cdep0), (uint32_t *)(A + o_cdep1) };
@@ -722,7 +1091,7 @@ int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want
 		}
 	}
 	out->nodes = nodes; out->hot = hot; out->cold = cold;
-	out->n_nodes = n - 1; out->n_tris = n;
+	out->n_nodes = n_rows; out->n_tris = n;
 	out->depth = h[6] + 1u; // pending entries on the deepest path + the sentinel
 	// 4-wide walk: every 4-wide node on a path leaves at most 3 entries pending and descends at least one binary level
 	out->nodes4 = nodes4; out->stack4 = nodes4 ? 3u * h[6] + 1u : 0u;

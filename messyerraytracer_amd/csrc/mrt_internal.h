@@ -174,9 +174,9 @@ struct DeviceBuildResult {
 	uint32_t n_nodes = 0, n_tris = 0, depth = 0, stack4 = 0, stack8 = 0;
 	float bounds_lo[3] = {0, 0, 0}, bounds_hi[3] = {0, 0, 0};
 };
-struct BuildArena { void *ptr = nullptr; size_t cap = 0; }; // the builder's temporaries: owned by the context, grown on demand
-// fast_lbvh: the radix tree over the Morton keys (fastest build); else PLOC (the better tree; the default)
-int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want8, bool safe_handoff, bool fast_lbvh, BuildArena *arena, void *stream,
+struct BuildArena { void *ptr = nullptr; size_t cap = 0; uint32_t *pinned = nullptr; }; // the builder's temporaries: owned by the context, grown on demand (pinned: 64 host bytes the per-level counters are read back into)
+// form: 0 the radix tree over the Morton keys (fastest build), 1 PLOC, 2 binned SAH (the host builder's tree; leaves of several triangles)
+int device_build_lbvh(const mrt_tri64 *d_tris, uint32_t n, bool want4, bool want8, bool safe_handoff, int form, BuildArena *arena, void *stream,
 		DeviceBuildResult *out, char *err, size_t err_len);
 
 // ---- two-level scene: SceneTLAS / MeshBLAS / BLASInstance

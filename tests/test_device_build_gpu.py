@@ -36,14 +36,17 @@ def _check(c, osc, name, masks=(0xFFFFFFFF,)):
     parity.assert_exact(c.cast_grid(cam, 100, 70), osc.trace(grid), f"{name} cast_grid")
 
 
-@pytest.mark.parametrize("ploc", [False, True], ids=["radix_tree", "ploc"])
+FORMS = {"radix_tree": {}, "ploc": {"ploc": True}, "sah": {"sah": True}}
+
+
+@pytest.mark.parametrize("form", list(FORMS))
 @pytest.mark.parametrize("n_tris,scale,seed", [(1, 2.0, 5), (2, 2.0, 6), (3, 1.5, 7), (17, 1.0, 8), (33, 1.0, 18), (1000, 0.5, 1), (20000, 0.25, 33)])
-def test_device_built_tree_gives_the_oracles_hits(built, n_tris, scale, seed, ploc):
+def test_device_built_tree_gives_the_oracles_hits(built, n_tris, scale, seed, form):
     v = synth.soup(n_tris, scale, seed)
     layers = (1 << (np.arange(n_tris) % 3)).astype(np.uint32)
     tris = capi.make_triangles(v, None, layers)
     c = capi.Context(0)
-    c.build_scene_device(tris, ploc=ploc)
+    c.build_scene_device(tris, **FORMS[form])
     assert c.is_available() and c.scene_info()["n_tris"] == n_tris
     _check(c, po.OracleScene(v, None, layers), f"n={n_tris}", masks=(0xFFFFFFFF, 0x5))
     c.close()
@@ -61,16 +64,17 @@ def test_every_kernel_walks_a_device_built_tree(built, kernel):
     c.close()
 
 
-@pytest.mark.parametrize("ploc", [False, True], ids=["radix_tree", "ploc"])
-def test_degenerate_inputs_for_the_device_builders(built, ploc):
+@pytest.mark.parametrize("form", list(FORMS))
+def test_degenerate_inputs_for_the_device_builders(built, form):
     """Equal Morton keys (coincident triangles, a flat cluster with one outlier): the radix tree splits them by
-    index, the clustering merges boxes of equal area by position; the tree stays a valid BVH of bounded depth."""
+    index, the clustering merges boxes of equal area by position, the SAH form keeps what no plane separates in one
+    leaf; the tree stays a valid BVH of bounded depth."""
     base = synth.soup(1, 0.5, 3)
     same = np.repeat(base, 300, axis=0)                       # 300 copies of one triangle: all keys equal
     v = np.concatenate([same, synth.soup(50, 0.2, 4) * 0.001, synth.soup(1, 0.5, 9) + 4.0]).astype(np.float32)
     ids = np.arange(v.shape[0], dtype=np.uint32)[::-1].copy()  # the winner among exact ties is the LOWEST id
     c = capi.Context(0)
-    c.build_scene_device(capi.make_triangles(v, ids), ploc=ploc)
+    c.build_scene_device(capi.make_triangles(v, ids), **FORMS[form])
     _check(c, po.OracleScene(v, ids), "degenerate")
     assert c.scene_info()["stack_need"] <= 64
     c.close()
@@ -101,6 +105,10 @@ def test_device_resident_triangles_and_rebuild(built):
     _check(c, po.OracleScene(v), "clustering after the radix tree")
     c.build_scene_device(capi.make_triangles(v))
     _check(c, po.OracleScene(v), "radix tree after clustering")
+    c.build_scene_device(capi.make_triangles(v), sah=True)       # ... and the binned-SAH form (its own, larger share of the arena)
+    _check(c, po.OracleScene(v), "SAH after the radix tree")
+    c.build_scene_device(capi.make_triangles(v), ploc=True)
+    _check(c, po.OracleScene(v), "clustering after SAH")
     # the builder's arena grows when a larger scene arrives (and is kept for the smaller ones after it)
     big = synth.soup(30000, 0.25, 12)
     c.build_scene_device(capi.make_triangles(big), ploc=True)
@@ -133,6 +141,30 @@ def test_c2_device_build_matches_host_build_on_the_full_grid(built):
     c.close()
 
 
+def test_the_sah_form_builds_the_host_builders_tree(built):
+    """MRT_BUILD_SAH makes the host builder's decisions (tinybvh::BVH::Build, restated in host/bvh_builder.cpp) on the
+    device's triangle boxes -- the host's widened by one ulp (v0 + e1 is a rounded sum) --, so the tree has the host
+    tree's shape: the same number of rows and the same stack need to within the handful of decisions an ulp can flip,
+    and the records of a cast are the same bytes."""
+    cfg = synth.CONFIGS["C2"]
+    w, h = cfg["grid"]
+    cam = capi.camera_look(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
+    c = capi.Context(0)
+    scene = capi.Scene(synth.scene_vertices(cfg))
+    scene.upload(c)
+    host_info, host = c.scene_info(), c.cast_grid(cam, w, h)
+    c.build_scene_device(scene.tris, sah=True)
+    info = c.scene_info()
+    assert abs(info["n_wide_nodes"] - host_info["n_wide_nodes"]) <= 0.002 * host_info["n_wide_nodes"], (info, host_info)
+    assert abs(info["stack_need"] - host_info["stack_need"]) <= 2
+    assert c.cast_grid(cam, w, h).tobytes() == host.tobytes()
+    inc = synth.incoherent_rays(1 << 18, 78)
+    got = c.cast(inc)
+    scene.upload(c)
+    assert got.tobytes() == c.cast(inc).tobytes()
+    c.close()
+
+
 def test_c3_c4_device_build_matches_host_build(built):
     """The headline scene (1 M triangles): 4096^2 primary rays (packet kernel) and 2^22 of C4's
     incoherent rays (persistent lane kernel; 2-wide on the device-built tree, 4-wide on the
@@ -152,6 +184,9 @@ def test_c3_c4_device_build_matches_host_build(built):
     assert c.cast_grid(cam, w, h).tobytes() == host_grid.tobytes()
     assert c.cast(inc, flags=capi.FLAG_COHERENT).tobytes() == host_inc.tobytes()
     assert c.cast(inc).tobytes() == host_inc.tobytes()      # Morton-sorted
+    c.build_scene_device(scene.tris, sah=True)               # the binned-SAH form: leaves of several triangles
+    assert c.cast_grid(cam, w, h).tobytes() == host_grid.tobytes()
+    assert c.cast(inc).tobytes() == host_inc.tobytes()
     c.close()
 
 

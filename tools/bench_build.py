@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build time and trace time: host-built 8-bin SAH tree (mrt_bvh2_build + mrt_upload_scene) against
-the device-built trees (mrt_build_scene_device: the radix tree, and PLOC with MRT_BUILD_PLOC), on one config's scene and primary-ray grid.
+the device-built trees (mrt_build_scene_device: the radix tree, PLOC with MRT_BUILD_PLOC, binned SAH with MRT_BUILD_SAH), on one config's scene and primary-ray grid.
 
     python tools/bench_build.py --config C3 [--rounds 5]
 """
@@ -64,30 +64,38 @@ def main():
     ctx.upload_scene(tris, nodes, prim_idx)
     t2 = time.perf_counter()
     out["host"] = dict(build_s=t1 - t0, upload_s=t2 - t1, threads=len(os.sched_getaffinity(0)),
-                       stack_need=ctx.scene_info()["stack_need"], trace_ms=trace_ms(), incoherent_4M_ms=incoherent_ms())
+                       stack_need=ctx.scene_info()["stack_need"], rows=ctx.scene_info()["n_wide_nodes"], trace_ms=trace_ms(), incoherent_4M_ms=incoherent_ms())
     host_hits = digest()
 
     # device: triangles from host memory (PCIe included in wall time), and already resident; the default form
     # (the radix tree) and locally-ordered clustering (MRT_BUILD_PLOC)
     d_tris = ctx.device_alloc(tris.nbytes)
     ctx.h2d(d_tris, tris)
-    for name, ploc in (("device", False), ("device_ploc", True)):
+    for name, kw in (("device", {}), ("device_ploc", {"ploc": True}), ("device_sah", {"sah": True})):
         walls, devs = [], []
         for _ in range(a.rounds):
             t0 = time.perf_counter()
-            ctx.build_scene_device(tris, ploc=ploc)
+            ctx.build_scene_device(tris, **kw)
             walls.append(time.perf_counter() - t0)
             devs.append(ctx.stats()["last_build_ms"])
         res = []
         for _ in range(a.rounds):
-            ctx.build_scene_device(d_tris, n_tris=n, on_device=True, ploc=ploc)
+            ctx.build_scene_device(d_tris, n_tris=n, on_device=True, **kw)
             res.append(ctx.stats()["last_build_ms"])
         out[name] = dict(build_ms_from_host_tris=float(np.median(devs)), wall_ms_from_host_tris=float(np.median(walls)) * 1e3,
-                         build_ms_resident_tris=float(np.median(res)), stack_need=ctx.scene_info()["stack_need"], trace_ms=trace_ms(),
-                         incoherent_4M_ms=incoherent_ms())
+                         build_ms_resident_tris=float(np.median(res)), stack_need=ctx.scene_info()["stack_need"], rows=ctx.scene_info()["n_wide_nodes"],
+                         trace_ms=trace_ms(), incoherent_4M_ms=incoherent_ms())
         out[name]["identical_hits"] = bool(digest().tobytes() == host_hits.tobytes())
         out[name]["trace_vs_host"] = out[name]["trace_ms"] / out["host"]["trace_ms"]
         out[name]["incoherent_vs_host"] = out[name]["incoherent_4M_ms"] / out["host"]["incoherent_4M_ms"]
+    # the host tree once more, now that the device has been busy for seconds (the first measurement above runs on a cold part):
+    # the ratios are taken against the faster of the two
+    ctx.upload_scene(tris, nodes, prim_idx)
+    out["host"]["trace_ms_again"], out["host"]["incoherent_4M_ms_again"] = trace_ms(), incoherent_ms()
+    ht, hi = min(out["host"]["trace_ms"], out["host"]["trace_ms_again"]), min(out["host"]["incoherent_4M_ms"], out["host"]["incoherent_4M_ms_again"])
+    for name in ("device", "device_ploc", "device_sah"):
+        out[name]["trace_vs_host"] = out[name]["trace_ms"] / ht
+        out[name]["incoherent_vs_host"] = out[name]["incoherent_4M_ms"] / hi
     ctx.build_scene_device(d_tris, n_tris=n, on_device=True)
     ctx.cast_grid(cam, w, h, hits=d_hits, flags=capi.FLAG_HITS_ON_DEVICE)
     out["identical_hits"] = bool(digest().tobytes() == host_hits.tobytes())
