@@ -316,7 +316,8 @@ int mrt_upload_scene(mrt_ctx *ctx, const mrt_tri64 *tris, uint32_t n_tris,
  * MRT_ERR_UNSUPPORTED if the tree comes out deeper than the traversal stack (build on the host). */
 enum {
 	MRT_BUILD_TRIS_ON_DEVICE = 1u << 0,
-	MRT_BUILD_BLAS_ON_DEVICE = 1u << 2, /* mrt_upload_two_level_scene: every mesh's BVH built on the device (LBVH) */
+	MRT_BUILD_BLAS_ON_DEVICE = 1u << 2, /* mrt_upload_two_level_scene: every mesh's BVH built on the device (the radix tree; with
+	                                       MRT_BUILD_SAH the binned-SAH tree) */
 	MRT_BUILD_SAFE_HANDOFF   = 1u << 1, /* radix tree: the bottom-up pass hands boxes between threads with an
 	                                       acquire-release counter from the start (3x slower).  Every build verifies its
 	                                       tree afterwards and falls back to this form by itself if a hand-off was stale. */

@@ -322,13 +322,13 @@ class Context:
         self._chk(self.L.mrt_build_instanced_scene_device(self.h, _ptr(verts9), n_mesh_tris, _np(instances), instances.shape[0],
                                                           BUILD_TRIS_ON_DEVICE if on_device else 0))
 
-    def upload_two_level_scene(self, verts9, instances, blas_on_device=False):
+    def upload_two_level_scene(self, verts9, instances, blas_on_device=False, sah=False):
         """SceneTLAS::build_tlas: one BLAS per distinct mesh, a TLAS over the instances (nothing is flattened)."""
         verts9 = np.ascontiguousarray(verts9, dtype=np.float32)
         instances = np.ascontiguousarray(instances)
         assert instances.dtype == T.INSTANCE
         self._chk(self.L.mrt_upload_two_level_scene(self.h, _np(verts9), verts9.size // 9, _np(instances), instances.shape[0],
-                                                    BUILD_BLAS_ON_DEVICE if blas_on_device else 0))
+                                                    (BUILD_BLAS_ON_DEVICE if blas_on_device else 0) | (BUILD_SAH if sah else 0)))
 
     def update_instances(self, instances):
         """SceneTLAS::refit_tlas: the same instances with new transforms."""
@@ -492,11 +492,11 @@ class Group:
         tris, nodes, prim_idx = np.ascontiguousarray(scene.tris), np.ascontiguousarray(scene.nodes), np.ascontiguousarray(scene.prim_idx, dtype=np.uint32)
         self._chk(self.L.mrt_group_upload_scene(self.h, _np(tris), tris.shape[0], _np(nodes), nodes.shape[0], _np(prim_idx)))
 
-    def upload_two_level_scene(self, verts9, instances, blas_on_device=False):
+    def upload_two_level_scene(self, verts9, instances, blas_on_device=False, sah=False):
         verts9 = np.ascontiguousarray(verts9, dtype=np.float32)
         instances = np.ascontiguousarray(instances)
         self._chk(self.L.mrt_group_upload_two_level_scene(self.h, _np(verts9), verts9.size // 9, _np(instances), instances.shape[0],
-                                                          BUILD_BLAS_ON_DEVICE if blas_on_device else 0))
+                                                          (BUILD_BLAS_ON_DEVICE if blas_on_device else 0) | (BUILD_SAH if sah else 0)))
 
     def cast_grid(self, cam, grid_w, grid_h, hits=None, query_mask=0xFFFFFFFF, mode=MODE_NEAREST, flags=0):
         if hits is None:

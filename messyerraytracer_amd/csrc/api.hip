@@ -845,7 +845,7 @@ int mrt_build_instanced_scene_device(mrt_ctx *ctx, const float *verts9, uint32_t
 // is moved to its place in the scene's arrays (node refs + node_base, leaf slots + tri_base).  h comes from
 // prepare_two_level(build_blas = false); on success the device arrays of ctx hold every BLAS and h knows
 // their boxes and depths.
-static int build_blases_on_device(mrt_ctx *ctx, mrt::TwoLevelHost *h, const float *verts9)
+static int build_blases_on_device(mrt_ctx *ctx, mrt::TwoLevelHost *h, const float *verts9, int form)
 {
 	uint32_t max_tris = 0;
 	for (uint32_t k = 0; k < h->n_blas; k++) if (h->blas[k].n_tris > max_tris) max_tris = h->blas[k].n_tris;
@@ -861,7 +861,7 @@ static int build_blases_on_device(mrt_ctx *ctx, mrt::TwoLevelHost *h, const floa
 		hipError_t e = hipMemcpy(staged, tris.data(), (size_t)bl.n_tris * sizeof(mrt_tri64), hipMemcpyHostToDevice);
 		if (e != hipSuccess) { rc = fail(ctx, MRT_ERR_HIP, hipGetErrorString(e)); break; }
 		mrt::DeviceBuildResult b;
-		rc = mrt::device_build_lbvh(staged, bl.n_tris, false, h->wide8, false, 0, &ctx->build_arena, (void *)ctx->stream, &b, ctx->err, sizeof(ctx->err));
+		rc = mrt::device_build_lbvh(staged, bl.n_tris, false, h->wide8, false, form, &ctx->build_arena, (void *)ctx->stream, &b, ctx->err, sizeof(ctx->err));
 		if (rc) break;
 		e = mrt::launch_offset_refs(ctx->d_nodes + bl.root, b.nodes, b.n_nodes, bl.root, tri_base, (void *)ctx->stream);
 		if (h->wide8 && !(b.nodes8 && b.leaf_box)) h->wide8 = false; // a mesh whose boxes fit no grid: the scene goes without the 8-wide layout
@@ -877,7 +877,8 @@ static int build_blases_on_device(mrt_ctx *ctx, mrt::TwoLevelHost *h, const floa
 		if (b.nodes8) (void)hipFree(b.nodes8);
 		if (b.leaf_box) (void)hipFree(b.leaf_box);
 		if (e != hipSuccess) { rc = fail(ctx, MRT_ERR_HIP, hipGetErrorString(e)); break; }
-		if (b.n_nodes != bl.n_tris - 1u) { rc = fail(ctx, MRT_ERR_BAD_BVH, "two-level scene: unexpected BLAS size"); break; }
+		// (the scene's node array holds n_tris - 1 rows per mesh: what the radix tree fills; the SAH form, with leaves of several triangles, fewer)
+		if (b.n_nodes == 0u || b.n_nodes > bl.n_tris - 1u) { rc = fail(ctx, MRT_ERR_BAD_BVH, "two-level scene: unexpected BLAS size"); break; }
 		bl.depth = b.depth;
 		for (int c = 0; c < 3; c++) { bl.lo[c] = b.bounds_lo[c]; bl.hi[c] = b.bounds_hi[c]; }
 		tri_base += bl.n_tris;
@@ -892,7 +893,8 @@ int mrt_upload_two_level_scene(mrt_ctx *ctx, const float *verts9, uint32_t n_mes
 {
 	if (!ctx) return MRT_ERR_INVALID;
 	if (!verts9 || !instances || n_instances == 0 || n_mesh_tris == 0) return fail(ctx, MRT_ERR_INVALID, "two-level scene: null or empty argument");
-	if (flags & ~(uint32_t)MRT_BUILD_BLAS_ON_DEVICE) return fail(ctx, MRT_ERR_INVALID, "two-level scene: unknown flag");
+	if (flags & ~(uint32_t)(MRT_BUILD_BLAS_ON_DEVICE | MRT_BUILD_SAH)) return fail(ctx, MRT_ERR_INVALID, "two-level scene: unknown flag");
+	if ((flags & MRT_BUILD_SAH) && !(flags & MRT_BUILD_BLAS_ON_DEVICE)) return fail(ctx, MRT_ERR_INVALID, "two-level scene: MRT_BUILD_SAH goes with MRT_BUILD_BLAS_ON_DEVICE (the host builder's trees are SAH trees)");
 	const bool on_device = (flags & MRT_BUILD_BLAS_ON_DEVICE) != 0;
 	int rc = drain_pending(ctx);
 	if (rc) return rc;
@@ -923,7 +925,7 @@ int mrt_upload_two_level_scene(mrt_ctx *ctx, const float *verts9, uint32_t n_mes
 	if (on_device) {
 		hipEvent_t e0 = ctx->ev[0], e1 = ctx->ev[1]; // the context's own events: nothing to create or to leak here
 		(void)hipEventRecord(e0, ctx->stream);
-		rc = build_blases_on_device(ctx, h, verts9);
+		rc = build_blases_on_device(ctx, h, verts9, (flags & MRT_BUILD_SAH) ? 2 : 0);
 		if (!rc) rc = mrt::refit_two_level(h, instances, n_instances, ctx->err, sizeof(ctx->err));
 		if (!rc && h->depth > 64u) rc = fail(ctx, MRT_ERR_UNSUPPORTED, "two-level scene: device-built trees too deep for the traversal stack: build on the host");
 		if (rc) { drop(); free_scene(ctx); return rc; }
@@ -1196,7 +1198,8 @@ static void tune_grid_kernel(mrt_ctx *ctx, mrt::TraceParams &p, int mode, uint32
 	auto &t = ctx->tune;
 	t.armed = false;
 	if (ctx->opts.kernel != MRT_KERNEL_AUTO || ctx->two_level || !ctx->d_rows || ctx->opts.count_visits || ctx->opts.tile_schedule == 1u) return;
-	if (p.lane_map != mrt::MAP_TILE8X8 || p.count < kScheduleMinRays || p.count >= kScheduleMaxRays) return;
+	// (from 2^22 rays on the 128-ray walk won every measurement -- 2560x1440 .. 7680x4320, C5's row blocks --: no frames are spent on the other one)
+	if (p.lane_map != mrt::MAP_TILE8X8 || p.count < kScheduleMinRays || p.count >= kScheduleMaxRays || p.count >= (1ull << 22)) return;
 	if (p.kernel != MRT_KERNEL_PACKET_ASM && p.kernel != MRT_KERNEL_PACKET_DUAL) return;
 	const bool same = t.grid_w == p.grid_w && t.grid_h == p.grid_h && t.y0 == p.y0 && t.rows == p.rows && t.mode == mode;
 	if (!same) { t.grid_w = p.grid_w; t.grid_h = p.grid_h; t.y0 = p.y0; t.rows = p.rows; t.mode = mode; t.phase = 0; t.t_asm = t.t_dual = 0.0f; }

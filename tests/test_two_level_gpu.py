@@ -161,13 +161,17 @@ def test_two_level_agrees_with_the_flattened_scene(built):
     c1.close(); c2.close()
 
 
-def test_blases_built_on_the_device(built):
-    """MRT_BUILD_BLAS_ON_DEVICE: every mesh's BVH from the device builder (LBVH) instead of the host SAH builder.
-    Different trees, the same hit records: a result does not depend on which valid BVH is walked."""
+@pytest.mark.parametrize("sah", [False, True], ids=["radix_tree", "sah"])
+def test_blases_built_on_the_device(built, sah):
+    """MRT_BUILD_BLAS_ON_DEVICE: every mesh's BVH from the device builder (the radix tree, or with MRT_BUILD_SAH the binned-SAH
+    tree) instead of the host SAH builder.  Different trees, the same hit records: a result does not depend on which valid
+    BVH is walked."""
     local, inst = _scene()
     osc = po.OracleTwoLevelScene(local, inst)
     c = capi.Context(0)
-    c.upload_two_level_scene(local, inst, blas_on_device=True)
+    with pytest.raises(capi.MrtError):
+        c.upload_two_level_scene(local, inst, sah=True)          # the flag goes with device-built BLASes only
+    c.upload_two_level_scene(local, inst, blas_on_device=True, sah=sah)
     assert c.stats()["last_build_ms"] > 0.0
     assert c.scene_info()["n_tris"] == 8 * 3000
     _check(c, osc, "device-built BLASes")
@@ -182,7 +186,7 @@ def test_blases_built_on_the_device(built):
     assert c.cast_grid(cam, 512, 512).tobytes() == h.cast_grid(cam, 512, 512).tobytes()
     one_local, one = synth.multi_mesh_instances(1, 1, 0.5, 3)     # a one-triangle mesh has no device-built tree
     with pytest.raises(capi.MrtError) as e:
-        c.upload_two_level_scene(one_local, one, blas_on_device=True)
+        c.upload_two_level_scene(one_local, one, blas_on_device=True, sah=sah)
     assert e.value.status == capi.ERR_UNSUPPORTED
     c.upload_two_level_scene(one_local, one)                      # ... the host builder wraps the root leaf
     rays = np.concatenate([po.grid_rays((0, 0, -12), (0, 0, 1), 64, 64, 50.0), synth.incoherent_rays(70000, 4)])
