@@ -1,5 +1,6 @@
 """Builds libmrt_hip.so (the C-ABI library: HIP kernels for gfx950 + host-side
 scene preparation) in-tree with hipcc.  hipcc cross-compiles without a GPU."""
+import concurrent.futures
 import os
 import shutil
 import subprocess
@@ -7,6 +8,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libmrt_hip.so")
+OBJ = os.path.join(HERE, "_obj")  # object files of the last build (git-ignored; not needed at run time)
 HOST_TEST = os.path.join(HERE, "host_mirror_test")
 HOST_CPU_TEST = os.path.join(HERE, "host_cpu_test")
 HOST_TLAS_TEST = os.path.join(HERE, "host_tlas_test")
@@ -43,12 +45,26 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     if force or _stale(LIB, deps):
         extra = ["-DMRT_WITH_QUAD"] if os.environ.get("MRT_WITH_QUAD") == "1" else []
-        cmd = [_hipcc()] + FLAGS + extra + ["-shared"] + srcs + ["-o", LIB, "-pthread"]
+        # one object per translation unit, compiled side by side (kernels.hip alone is over a minute), then one link
+        os.makedirs(OBJ, exist_ok=True)
+        objs = [os.path.join(OBJ, s.replace("/", "_") + ".o") for s in SOURCES]
+
+        def compile_one(job):
+            src, obj = job
+            cmd = [_hipcc()] + FLAGS + extra + ["-c", src, "-o", obj]
+            r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
+            if r.returncode != 0:
+                raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+            return r.stderr
+
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(srcs), os.cpu_count() or 1)) as pool:
+            logs = list(pool.map(compile_one, zip(srcs, objs)))
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", LIB, "-pthread"]
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=CSRC)
         if r.returncode != 0:
-            raise RuntimeError("hipcc failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+            raise RuntimeError("hipcc link failed:\n" + " ".join(cmd) + "\n" + r.stdout + r.stderr)
         if verbose:
-            print(r.stderr)
+            print("".join(logs) + r.stderr)
     return LIB
 
 
