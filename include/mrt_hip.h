@@ -253,9 +253,10 @@ typedef struct mrt_options {
 	                             cull): 0 = library default (since round 3: on for rays generated in the kernel, mrt_cast_grid -- 14 % fewer
 	                             vector instructions, C3 1.5 %, C5 3 % faster --, off for rays read from memory, where the walk
 	                             with the scalar-cache prefetch is 2 % faster), 1 = off, 2 = on */
-	uint32_t tile_schedule;   /* grid casts of 2^15 .. 2^23 rays: 0 = launch the tiles longest first by what each cost in the last cast of
+	uint32_t tile_schedule;   /* grid casts of 2^19 .. 2^24 rays: 0 = launch the tiles longest first by what each cost in the last cast of
 	                             the same grid (every wave notes its shader cycles; a radix sort on a side stream makes the order;
-	                             the first cast of a grid runs in the plain order); 1 = always the plain order */
+	                             the first cast of a grid runs in the plain order), the few units that would end the frame alone in
+	                             pieces (single tiles, quarter tiles); 1 = always the plain order; 2 = longest first, no pieces */
 } mrt_options;
 
 typedef struct mrt_ctx mrt_ctx;

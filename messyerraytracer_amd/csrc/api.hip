@@ -81,23 +81,25 @@ struct mrt_ctx {
 	// Frame-coherent tile schedule of grid casts: what every schedule unit (one 8x8 tile, or the two of a 128-ray wave)
 	// cost in the last cast of this grid, and the launch order made of it (longest first); see schedule_grid().
 	struct TileSchedule {
-		uint32_t grid_w = 0, grid_h = 0, y0 = 0, rows = 0, unit = 0, n_units = 0, tile_w_log2 = 0;
+		uint32_t grid_w = 0, grid_h = 0, y0 = 0, rows = 0, unit = 0, n_units = 0, tile_w_log2 = 0; bool pieces = false;
 		// two generations: frame f notes its costs in cost[f & 1] and the side stream sorts them into order[f & 1] while frame
 		// f + 1 (launched in the order of frame f - 1) already runs: back-to-back frames never wait for a sort
 		uint32_t frame = 0, gen = 0;       // frames of this grid, sorts issued for it
 		bool measuring = false;            // this frame notes its costs (and is sorted afterwards)
 		bool have_order[2] = {false, false};
 		DevBuf cost[2], order[2], cost_sorted, iota, tmp;
+		DevBuf slots[2], hdr[2];           // what is launched: the order with its most expensive units in pieces (schedule_split)
+		uint32_t n_slots_max = 0;
 		hipStream_t side = nullptr;
 		hipEvent_t traced = nullptr, ready[2] = {nullptr, nullptr};
 		void forget() { have_order[0] = have_order[1] = false; }
 	} sched;
-	// Which of the two packet kernels a mid-size grid takes is MEASURED per grid (tune_grid_kernel): frames 0-2 run the 64-ray
-	// kernel (plain order, then scheduled), frames 3-5 the 128-ray walk, and from frame 6 on the faster of the two third
-	// frames is kept (the better one flips with the number of rounds a grid makes on the chip: 1280x960 0.33 against 0.37 ms
-	// for the 128-ray walk, 1920x1080 0.59 against 0.44).
+	// How a mid-size grid is cast is MEASURED per grid (tune_grid_kernel): four frames with the 64-ray kernel, four with the 128-ray
+	// walk and its most expensive units launched in pieces, four with the 128-ray walk and every unit whole; from frame 12 on the
+	// fastest of the three, each judged by the faster of its last two frames.  What wins flips with the number of rounds a grid
+	// makes on the chip (C3 scene: 1280x720 the 64-ray kernel, 1280x960 the 128-ray walk whole, 1920x1080 the 128-ray walk in pieces).
 	uint64_t last_detect_count = 0;   // rays of the last cast whose row width was looked for on the device (h_auto holds what it found)
-	struct GridTune { uint32_t grid_w = 0, grid_h = 0, y0 = 0, rows = 0; int mode = -1; int phase = 0; float t_asm = 0.0f, t_dual = 0.0f; bool armed = false; } tune;
+	struct GridTune { uint32_t grid_w = 0, grid_h = 0, y0 = 0, rows = 0; int mode = -1; int phase = 0; float t_asm = 0.0f, t_dual = 0.0f, t_whole = 0.0f; bool armed = false, no_pieces = false; } tune;
 	char queued_variant[96] = "", queued_alt_variant[96] = "", last_variant[96] = ""; // instantiation names (mrt_last_kernel_variant)
 	uint32_t queued_kernel = 0, queued_alt_kernel = 0; bool queued_detect = false; // what the last enqueue_cast put on the stream
 	// host-array pipeline (cast_host_pipelined): copy streams and per-chunk events, created on first use
@@ -287,6 +289,7 @@ int device_sort(mrt_ctx *ctx, const void *d_rays, uint32_t in_fmt, uint64_t coun
 
 } // namespace
 // (defined with the grid casts below)
+constexpr int kTuneFrames = 4; // frames per candidate of the grid kernel tuner (tune_grid_kernel): the last two are timed
 static bool schedule_applies(const mrt_ctx *ctx, const mrt::TraceParams &p);
 static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p);
 static int schedule_sort(mrt_ctx *ctx);
@@ -395,7 +398,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 		mrt::TraceParams g = p;
 		g.grid_w = ctx->h_auto[0]; g.rows = ctx->h_auto[1]; g.grid_h = g.rows; g.y0 = 0; g.tiles_x = ctx->h_auto[2];
 		if ((rc = schedule_grid(ctx, g))) return rc;
-		p.tile_sched = g.tile_sched; p.tile_cost = g.tile_cost; p.tile_unit = g.tile_unit; p.n_units = g.n_units;
+		p.tile_sched = g.tile_sched; p.tile_cost = g.tile_cost; p.tile_unit = g.tile_unit; p.n_units = g.n_units; p.sched_hdr = g.sched_hdr; p.n_slots_max = g.n_slots_max;
 		scheduled = true;
 	}
 	ctx->last_detect_count = detect ? count : 0;
@@ -595,7 +598,7 @@ int mrt_create(int device_ordinal, const mrt_options *opts, mrt_ctx **out)
 	*out = nullptr;
 	if (opts && opts->struct_size != sizeof(mrt_options)) return MRT_ERR_INVALID;
 	if (opts && opts->kernel == MRT_KERNEL_PACKET_QUAD && !mrt::quad_kernel_built()) return MRT_ERR_UNSUPPORTED; // not in this build (MRT_WITH_QUAD)
-	if (opts && ((opts->packet_wg != 0u && opts->packet_wg != 64u && opts->packet_wg != 256u) || opts->packet_cull > 2u || opts->tile_schedule > 1u || opts->kernel > MRT_KERNEL_PACKET_QUAD || opts->kernel == 3u || opts->kernel == 4u)) return MRT_ERR_INVALID; // 3, 4: retired ids
+	if (opts && ((opts->packet_wg != 0u && opts->packet_wg != 64u && opts->packet_wg != 256u) || opts->packet_cull > 2u || opts->tile_schedule > 2u || opts->kernel > MRT_KERNEL_PACKET_QUAD || opts->kernel == 3u || opts->kernel == 4u)) return MRT_ERR_INVALID; // 3, 4: retired ids
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || device_ordinal < 0 || device_ordinal >= n) return MRT_ERR_NO_DEVICE;
 	mrt_ctx *ctx = new (std::nothrow) mrt_ctx();
@@ -1102,7 +1105,62 @@ int mrt_has_pending(const mrt_ctx *ctx) { return ctx && ctx->pending ? 1 : 0; }
 #ifndef MRT_SCHEDULE_MAX_LOG2
 #define MRT_SCHEDULE_MAX_LOG2 24
 #endif
-constexpr uint64_t kScheduleMinRays = 1ull << 19, kScheduleMaxRays = 1ull << MRT_SCHEDULE_MAX_LOG2; // 640x360 (2^17.8 rays) measured slower with it
+constexpr uint64_t kScheduleMaxRays = 1ull << MRT_SCHEDULE_MAX_LOG2;
+// 2^19: 640x360 (2^17.8 rays) measured slower with it.  MRT_SCHEDULE_MIN_LOG2 lowers the bound (the tests schedule small grids)
+static uint64_t schedule_min_rays()
+{
+	const char *e = std::getenv("MRT_SCHEDULE_MIN_LOG2"); // (read per cast: a test sets it for its own contexts)
+	const int k = e ? std::atoi(e) : 19;
+	return 1ull << (k >= 12 && k <= 24 ? k : 19);
+}
+#define kScheduleMinRays schedule_min_rays()
+// The launch list of a generation: the sorted order, with the units whose cost says they would end the frame alone launched in
+// pieces (TraceParams::tile_sched).  A frame of 1-2 M rays is one or two rounds of waves, so it lasts as long as its longest
+// walk, and the cost arrays say the longest walks are few and far out: at 1920x1080 on the C3 scene one pair of tiles takes
+// 1.4 M cycles, the 99th percentile 0.57 M, and all pairs together 0.68 M per wave slot.  A unit above BOTH the work per wave
+// slot and the cost of rank n / 100 goes in quarter tiles (4x4 pixels in 16 lanes; eight of them for a pair: each takes
+// 0.18 of the pair, all eight 1.5 x the pair); pieces first, so the longest things still start first.  Whether that pays
+// depends on how many rounds of waves the frame is: 1920x1080 (two rounds of pairs) 0.60 -> 0.37 ms, 1280x960 (1.2 rounds)
+// 0.323 -> 0.337 ms -- every extra wave pushes a whole unit into the second round, and the pieces' work is half again their
+// unit's; a deeper cut (the work per wave slot alone as the bound) 0.378 ms, only far outliers (1.25 x the 99th percentile)
+// nothing at 1280x960 and 0.43 ms at 1920x1080.  So the rule stays simple and the kernel tuner MEASURES it: a grid's frames
+// 3-5 run the 128-ray walk with pieces, 6-8 without, and the faster way is kept (tune_grid_kernel).
+// hdr = {units in quarters, units in single tiles (unused: 0), slots}.  MRT_SCHED_SPLIT_PCT: the rank, in percent (default 1).
+constexpr uint32_t kWaveSlots = 256u * 4u * 8u; // wave slots of the device (CUs x SIMDs x waves): what a frame's work is spread over
+__global__ __launch_bounds__(1024) void schedule_plan_kernel(const uint32_t *cost_sorted, uint32_t n_units, uint32_t unit, uint32_t n_extra, uint32_t rank, uint32_t *hdr)
+{
+	__shared__ unsigned long long part[16];
+	unsigned long long sum = 0ull;
+	for (uint32_t i = threadIdx.x; i < n_units; i += 1024u) sum += cost_sorted[i];
+	for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+	if ((threadIdx.x & 63u) == 0u) part[threadIdx.x >> 6] = sum;
+	__syncthreads();
+	if (threadIdx.x != 0u) return;
+	sum = 0ull;
+	for (int w = 0; w < 16; w++) sum += part[w];
+	unsigned long long thr = sum / kWaveSlots;
+	if (rank < n_units && (unsigned long long)cost_sorted[rank] > thr) thr = cost_sorted[rank];
+	// cost_sorted is descending: how many lie above the bound
+	uint32_t lo = 0u, hi = n_units;
+	while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((unsigned long long)cost_sorted[mid] > thr) lo = mid + 1u; else hi = mid; }
+	const uint32_t per_quartered = unit == 2u ? 7u : 3u; // extra slots of a unit in quarters
+	uint32_t quartered = sum == 0ull ? 0u : lo;
+	if ((unsigned long long)quartered * per_quartered > n_extra) quartered = n_extra / per_quartered;
+	hdr[0] = quartered; hdr[1] = 0u; hdr[2] = n_units + quartered * per_quartered;
+}
+__global__ __launch_bounds__(256) void schedule_fill_kernel(const uint32_t *order, uint32_t n_units, uint32_t unit, const uint32_t *hdr, uint32_t *slots)
+{
+	const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+	if (i >= n_units) return;
+	const uint32_t quartered = hdr[0], halved = hdr[1], u = order[i], pieces = unit == 2u ? 8u : 4u;
+	if (i < quartered) {
+		for (uint32_t k = 0; k < pieces; k++) slots[i * pieces + k] = ((2u + (k & 3u)) << 28) | (u * unit + (k >> 2));
+	} else if (i < quartered + halved) {
+		const uint32_t at = quartered * pieces + (i - quartered) * 2u;
+		slots[at] = (1u << 28) | (u * 2u); slots[at + 1u] = (1u << 28) | (u * 2u + 1u);
+	} else slots[quartered * pieces + halved * 2u + (i - quartered - halved)] = u;
+}
+
 static bool schedule_applies(const mrt_ctx *ctx, const mrt::TraceParams &p)
 {
 	if (ctx->opts.tile_schedule == 1u || ctx->opts.count_visits) return false;
@@ -1122,8 +1180,10 @@ static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p)
 	const uint32_t unit = p.kernel == MRT_KERNEL_PACKET_DUAL ? 2u : 1u;
 	const uint64_t tiles = (uint64_t)p.tiles_x * tiles_y;
 	const uint32_t n_units = (uint32_t)((tiles + unit - 1u) / unit);
+	// pieces: 8x8 tiles only, ids within the entry's 28 bits, not while the kernel tuner tries (or has chosen) the frames without
+	const bool pieces = p.tile_w_log2 == 3u && ctx->opts.tile_schedule != 2u && tiles < (1ull << 28) && !ctx->tune.no_pieces;
 	const bool same = s.grid_w == p.grid_w && s.grid_h == p.grid_h && s.y0 == p.y0 && s.rows == p.rows && s.unit == unit &&
-			s.n_units == n_units && s.tile_w_log2 == p.tile_w_log2;
+			s.n_units == n_units && s.tile_w_log2 == p.tile_w_log2 && s.pieces == pieces;
 	int rc;
 	if (!s.side) {
 		HIP_TRY(ctx, hipStreamCreateWithFlags(&s.side, hipStreamNonBlocking));
@@ -1132,8 +1192,10 @@ static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p)
 	}
 	if (!same) {
 		HIP_TRY(ctx, hipStreamSynchronize(s.side)); // no sort of the old grid may still use the arrays
+		s.n_slots_max = pieces ? n_units + n_units / 2u : n_units; // at most half as many extra slots as there are units
 		for (int k = 0; k < 2; k++)
-			if ((rc = ensure(ctx, s.cost[k], (size_t)n_units * 4)) || (rc = ensure(ctx, s.order[k], (size_t)n_units * 4))) return rc;
+			if ((rc = ensure(ctx, s.cost[k], ((size_t)n_units + s.n_slots_max) * 4)) || (rc = ensure(ctx, s.order[k], (size_t)n_units * 4)) ||
+					(rc = ensure(ctx, s.slots[k], (size_t)s.n_slots_max * 4)) || (rc = ensure(ctx, s.hdr[k], 16))) return rc;
 		if ((rc = ensure(ctx, s.cost_sorted, (size_t)n_units * 4)) || (rc = ensure(ctx, s.iota, (size_t)n_units * 4))) return rc;
 		std::vector<uint32_t> iota(n_units);
 		for (uint32_t i = 0; i < n_units; i++) iota[i] = i;
@@ -1142,20 +1204,22 @@ static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p)
 		s.forget();
 		s.frame = 0; s.gen = 0;
 	}
-	s.grid_w = p.grid_w; s.grid_h = p.grid_h; s.y0 = p.y0; s.rows = p.rows; s.unit = unit; s.n_units = n_units; s.tile_w_log2 = p.tile_w_log2;
+	s.grid_w = p.grid_w; s.grid_h = p.grid_h; s.y0 = p.y0; s.rows = p.rows; s.unit = unit; s.n_units = n_units; s.tile_w_log2 = p.tile_w_log2; s.pieces = pieces;
 	const uint32_t cur = s.gen & 1u, newest = cur ^ 1u;     // the slot the next generation goes to, the slot of the last one
 	// the order to launch in: the last generation's if its sort is done, else the one before (still intact in slot `cur`:
 	// that slot's ORDER array is rewritten only by the next sort, which runs after this frame's trace)
-	const uint32_t *order = nullptr;
-	if (s.have_order[newest] && hipEventQuery(s.ready[newest]) == hipSuccess) order = (const uint32_t *)s.order[newest].ptr;
+	// the frame the kernel tuner times (the third of a kernel) waits for the sorts behind it: it is launched the way later frames will be
+	if (ctx->tune.armed && ctx->tune.phase % kTuneFrames >= kTuneFrames - 2) HIP_TRY(ctx, hipStreamSynchronize(s.side));
+	const uint32_t *order = nullptr, *hdr = nullptr;
+	if (s.have_order[newest] && hipEventQuery(s.ready[newest]) == hipSuccess) { order = (const uint32_t *)s.slots[newest].ptr; hdr = (const uint32_t *)s.hdr[newest].ptr; }
 	(void)hipGetLastError(); // (hipErrorNotReady is not an error)
-	if (!order && s.have_order[cur] && hipEventQuery(s.ready[cur]) == hipSuccess) order = (const uint32_t *)s.order[cur].ptr;
+	if (!order && s.have_order[cur] && hipEventQuery(s.ready[cur]) == hipSuccess) { order = (const uint32_t *)s.slots[cur].ptr; hdr = (const uint32_t *)s.hdr[cur].ptr; }
 	(void)hipGetLastError();
 	// a measuring frame: the first two of a grid, then every kScheduleRenew-th -- if the slot's previous sort is done
 	s.measuring = (s.gen < 2u || s.frame % kScheduleRenew == 0u) && (!s.have_order[cur] || hipEventQuery(s.ready[cur]) == hipSuccess);
 	(void)hipGetLastError();
 	if (s.measuring) HIP_TRY(ctx, hipMemsetAsync(s.cost[cur].ptr, 0, (size_t)n_units * 4, ctx->stream));
-	p.tile_sched = order;
+	p.tile_sched = order; p.sched_hdr = hdr; p.n_slots_max = order ? s.n_slots_max : 0u;
 	p.tile_cost = s.measuring ? (uint32_t *)s.cost[cur].ptr : nullptr;
 	p.tile_unit = unit; p.n_units = n_units;
 	return MRT_OK;
@@ -1177,16 +1241,24 @@ static int schedule_sort(mrt_ctx *ctx)
 	int rc;
 	if (s.tmp.cap < tmp_bytes) { HIP_TRY(ctx, hipStreamSynchronize(s.side)); if ((rc = ensure(ctx, s.tmp, tmp_bytes))) return rc; }
 	HIP_TRY(ctx, rocprim::radix_sort_pairs_desc(s.tmp.ptr, tmp_bytes, ki, ko, vi, vo, (size_t)s.n_units, 0, 32, s.side));
+	uint32_t split_pct = 1u;
+	if (const char *e = std::getenv("MRT_SCHED_SPLIT_PCT")) { const int v = std::atoi(e); if (v >= 0 && v <= 50) split_pct = (uint32_t)v; } // tuning knob (tools/bench_resolutions.py)
+	hipLaunchKernelGGL(schedule_plan_kernel, dim3(1), dim3(1024), 0, s.side, ko, s.n_units, s.unit, s.n_slots_max - s.n_units, (uint32_t)((uint64_t)s.n_units * split_pct / 100u),
+			(uint32_t *)s.hdr[cur].ptr);
+	hipLaunchKernelGGL(schedule_fill_kernel, dim3((s.n_units + 255u) / 256u), dim3(256), 0, s.side, vo, s.n_units, s.unit, (const uint32_t *)s.hdr[cur].ptr, (uint32_t *)s.slots[cur].ptr);
+	HIP_TRY(ctx, hipGetLastError());
 	HIP_TRY(ctx, hipEventRecord(s.ready[cur], s.side));
 	s.have_order[cur] = true;
 	s.gen++;
 	if (std::getenv("MRT_SCHED_DUMP")) { // diagnosis: what the schedule was made of (tools/bench_resolutions.py with MRT_SCHED_DUMP=1)
 		std::vector<uint32_t> c(s.n_units);
+		uint32_t hdr[3] = {0, 0, 0};
 		HIP_TRY(ctx, hipStreamSynchronize(s.side));
 		HIP_TRY(ctx, hipMemcpy(c.data(), s.cost_sorted.ptr, (size_t)s.n_units * 4, hipMemcpyDeviceToHost));
+		HIP_TRY(ctx, hipMemcpy(hdr, s.hdr[cur].ptr, sizeof(hdr), hipMemcpyDeviceToHost));
 		unsigned long long sum = 0; for (uint32_t v : c) sum += v;
-		std::fprintf(stderr, "[mrt schedule] %ux%u unit %u: %u units, cycles sum %llu, max %u, p99 %u, median %u, min %u\n", s.grid_w, s.rows, s.unit,
-				s.n_units, sum, c.empty() ? 0u : c[0], c.empty() ? 0u : c[s.n_units / 100], c.empty() ? 0u : c[s.n_units / 2], c.empty() ? 0u : c[s.n_units - 1]);
+		std::fprintf(stderr, "[mrt schedule] %ux%u unit %u: %u units, cycles sum %llu, max %u, p99 %u, median %u, min %u; next launch: %u units in quarter tiles, %u slots\n", s.grid_w, s.rows, s.unit,
+				s.n_units, sum, c.empty() ? 0u : c[0], c.empty() ? 0u : c[s.n_units / 100], c.empty() ? 0u : c[s.n_units / 2], c.empty() ? 0u : c[s.n_units - 1], hdr[0], hdr[2]);
 	}
 	return MRT_OK;
 }
@@ -1196,24 +1268,35 @@ static int schedule_sort(mrt_ctx *ctx)
 static void tune_grid_kernel(mrt_ctx *ctx, mrt::TraceParams &p, int mode, uint32_t flags)
 {
 	auto &t = ctx->tune;
-	t.armed = false;
+	t.armed = false; t.no_pieces = false;
 	if (ctx->opts.kernel != MRT_KERNEL_AUTO || ctx->two_level || !ctx->d_rows || ctx->opts.count_visits || ctx->opts.tile_schedule == 1u) return;
 	// (from 2^22 rays on the 128-ray walk won every measurement -- 2560x1440 .. 7680x4320, C5's row blocks --: no frames are spent on the other one)
 	if (p.lane_map != mrt::MAP_TILE8X8 || p.count < kScheduleMinRays || p.count >= kScheduleMaxRays || p.count >= (1ull << 22)) return;
 	if (p.kernel != MRT_KERNEL_PACKET_ASM && p.kernel != MRT_KERNEL_PACKET_DUAL) return;
 	const bool same = t.grid_w == p.grid_w && t.grid_h == p.grid_h && t.y0 == p.y0 && t.rows == p.rows && t.mode == mode;
-	if (!same) { t.grid_w = p.grid_w; t.grid_h = p.grid_h; t.y0 = p.y0; t.rows = p.rows; t.mode = mode; t.phase = 0; t.t_asm = t.t_dual = 0.0f; }
-	if (t.phase < 3) p.kernel = MRT_KERNEL_PACKET_ASM;
-	else if (t.phase < 6) p.kernel = MRT_KERNEL_PACKET_DUAL;
-	else p.kernel = t.t_dual < t.t_asm ? MRT_KERNEL_PACKET_DUAL : MRT_KERNEL_PACKET_ASM;
-	t.armed = t.phase < 6 && !(flags & MRT_FLAG_ASYNC);   // an ASYNC cast has no timing: the phase waits for a blocking one
+	if (!same) { t.grid_w = p.grid_w; t.grid_h = p.grid_h; t.y0 = p.y0; t.rows = p.rows; t.mode = mode; t.phase = 0; t.t_asm = t.t_dual = t.t_whole = 0.0f; }
+	// frames 0-3: the 64-ray kernel; 4-7: the 128-ray walk, its most expensive units in pieces (schedule_plan_kernel); 8-11: the
+	// same with every unit whole; then the fastest of the three (each by the faster of its last two frames)
+	if (t.phase < kTuneFrames) p.kernel = MRT_KERNEL_PACKET_ASM;
+	else if (t.phase < 2 * kTuneFrames) p.kernel = MRT_KERNEL_PACKET_DUAL;
+	else if (t.phase < 3 * kTuneFrames) { p.kernel = MRT_KERNEL_PACKET_DUAL; t.no_pieces = true; }
+	else {
+		const bool whole = t.t_whole <= t.t_dual * 1.03f; // (pieces must win by more than the noise of two timings)
+		const float best_dual = whole ? t.t_whole : t.t_dual;
+		p.kernel = best_dual < t.t_asm ? MRT_KERNEL_PACKET_DUAL : MRT_KERNEL_PACKET_ASM;
+		t.no_pieces = p.kernel == MRT_KERNEL_PACKET_DUAL && whole;
+	}
+	t.armed = t.phase < 3 * kTuneFrames && !(flags & MRT_FLAG_ASYNC);   // an ASYNC cast has no timing: the phase waits for a blocking one
 }
 static void tune_record(mrt_ctx *ctx)
 {
 	auto &t = ctx->tune;
 	if (!t.armed) return;
-	if (t.phase == 2) t.t_asm = ctx->stats.last_trace_ms;   // (the third frame of a kernel: launched in a measured order)
-	if (t.phase == 5) t.t_dual = ctx->stats.last_trace_ms;
+	// the faster of a candidate's last two frames (both launched in a measured order: schedule_grid waits for the sorts behind them)
+	const int cand = t.phase / kTuneFrames, at = t.phase % kTuneFrames;
+	float &slot = cand == 0 ? t.t_asm : (cand == 1 ? t.t_dual : t.t_whole);
+	if (at == kTuneFrames - 2) slot = ctx->stats.last_trace_ms;
+	if (at == kTuneFrames - 1 && ctx->stats.last_trace_ms < slot) slot = ctx->stats.last_trace_ms;
 	t.phase++;
 	t.armed = false;
 }

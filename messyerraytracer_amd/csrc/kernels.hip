@@ -97,10 +97,17 @@ __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t 
 		const uint32_t tiles_y = (rows + (64u >> k) - 1u) >> (6u - k);
 		// the schedule of the previous frame: launch slot -> unit of tile_unit consecutive tiles.  Only if it is a schedule
 		// of THIS grid (a batch whose row width is found on the device, MAP_AUTO, was scheduled from the last cast's width)
+		uint32_t quarter = 4u; // 0..3: the slot's wave works on that 4x4 quarter of its tile, in lanes 0..15
 		if (p.tile_sched != nullptr && ((uint64_t)tiles_x * tiles_y + p.tile_unit - 1u) / p.tile_unit == p.n_units) {
 			const uint64_t slot = tile / p.tile_unit;
-			if (slot >= p.n_units) return false;
-			tile = (uint64_t)p.tile_sched[slot] * p.tile_unit + tile % p.tile_unit;
+			if (slot >= (p.sched_hdr ? p.sched_hdr[2] : p.n_units)) return false;
+			const uint32_t e = p.tile_sched[slot], what = e >> 28, id = e & 0x0FFFFFFFu;
+			if (what == 0u) tile = (uint64_t)id * p.tile_unit + tile % p.tile_unit;
+			else {
+				if (tile % p.tile_unit != 0u) return false; // a piece is (part of) one tile: a second group of the wave has nothing to do
+				tile = id;
+				if (what >= 2u) { quarter = what - 2u; if (l >= 16u) return false; }
+			}
 		}
 		if (p.tile_order == 1u && (tiles_x & 15u) == 0u && (tiles_y & 15u) == 0u) {
 			// 16x16-tile super-tiles in row-major order, Z-order inside: the tiles in flight at
@@ -121,8 +128,13 @@ __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t 
 			tx = (stx << 5) + mx; ty = (sty << 5) + my;
 		} else if (p.tile_order == 3u && xcd_strips(p, tile, tiles_x, tiles_y, tx, ty)) {
 		} else { tx = (uint32_t)(tile % tiles_x); ty = (uint32_t)(tile / tiles_x); }
-		px = (tx << k) + (l & ((1u << k) - 1u));
-		py = (ty << (6u - k)) + (l >> k);
+		if (quarter < 4u) { // (schedule pieces exist for 8x8 tiles only: k == 3)
+			px = (tx << 3) + ((quarter & 1u) << 2) + (l & 3u);
+			py = (ty << 3) + ((quarter >> 1) << 2) + (l >> 2);
+		} else {
+			px = (tx << k) + (l & ((1u << k) - 1u));
+			py = (ty << (6u - k)) + (l >> k);
+		}
 		if (px >= grid_w || py >= rows) return false;
 		ray_idx = (uint64_t)py * grid_w + px;
 		return true;
@@ -136,7 +148,7 @@ __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t 
 // What a wave's schedule unit cost (shader cycles, modulo 2^32), for the next frame's longest-first launch order.  The
 // start time is parked in the cost word itself (note_tile_start) and replaced by the difference at the end
 // (note_tile_cost): nothing stays in registers across the walk.  One lane per wave calls; a unit belongs to one wave.
-__device__ __forceinline__ bool tile_cost_word(const TraceParams &p, uint64_t g_first, uint32_t *&word)
+__device__ __forceinline__ bool tile_cost_word(const TraceParams &p, uint64_t g_first, uint32_t *&park, uint32_t *&sum, uint32_t &what)
 {
 	if (p.tile_cost == nullptr) return false;
 	uint32_t rows = p.rows, tiles_x = p.tiles_x;
@@ -144,21 +156,35 @@ __device__ __forceinline__ bool tile_cost_word(const TraceParams &p, uint64_t g_
 	else if (p.lane_map != MAP_TILE8X8) return false;
 	const uint32_t k = p.tile_w_log2, tiles_y = (rows + (64u >> k) - 1u) >> (6u - k);
 	if (((uint64_t)tiles_x * tiles_y + p.tile_unit - 1u) / p.tile_unit != p.n_units) return false; // not the grid the arrays were sized for
-	uint64_t unit = (g_first >> 6) / p.tile_unit;
-	if (unit >= p.n_units) return false;
-	if (p.tile_sched != nullptr) unit = p.tile_sched[unit];
-	word = p.tile_cost + unit;
+	const uint64_t slot = (g_first >> 6) / p.tile_unit;
+	what = 0u;
+	if (p.tile_sched == nullptr) { if (slot >= p.n_units) return false; park = sum = p.tile_cost + slot; return true; }
+	if (slot >= (p.sched_hdr ? p.sched_hdr[2] : p.n_units)) return false;
+	const uint32_t e = p.tile_sched[slot], id = e & 0x0FFFFFFFu;
+	what = e >> 28;
+	if (what == 0u) { park = sum = p.tile_cost + id; return true; }
+	park = p.tile_cost + p.n_units + slot; // a piece of a unit: its own word for the start time, its share added to the unit's
+	sum = p.tile_cost + id / p.tile_unit;
 	return true;
 }
 __device__ __forceinline__ void note_tile_start(const TraceParams &p, uint64_t g_first)
 {
-	uint32_t *w;
-	if (tile_cost_word(p, g_first, w)) *w = (uint32_t)__builtin_amdgcn_s_memtime();
+	uint32_t *park, *sum, what;
+	if (tile_cost_word(p, g_first, park, sum, what)) *park = (uint32_t)__builtin_amdgcn_s_memtime();
 }
+// A unit launched in pieces notes what it would have cost in one piece, as well as that can be said: two single tiles take
+// about 1.3 x their pair, the eight quarter tiles of a pair 1.5 x the pair, the four of a tile 1.15 x the tile (MRT_SCHED_DUMP
+// of consecutive renewals of one grid, 1920x1080 on the C3 scene: the same pair 1.43 M cycles whole, 1.82 M as two tiles,
+// 2.1 M as eight quarters) -- so that a unit is ranked as what it is, not as the sum of its pieces.
 __device__ __forceinline__ void note_tile_cost(const TraceParams &p, uint64_t g_first)
 {
-	uint32_t *w;
-	if (tile_cost_word(p, g_first, w)) { const uint32_t d = (uint32_t)__builtin_amdgcn_s_memtime() - *w; *w = d ? d : 1u; }
+	uint32_t *park, *sum, what;
+	if (!tile_cost_word(p, g_first, park, sum, what)) return;
+	uint32_t d = (uint32_t)__builtin_amdgcn_s_memtime() - *park;
+	if (park == sum) { *sum = d ? d : 1u; return; }
+	if (what == 1u) d = d - (d >> 2);                                  // x 3/4
+	else d = p.tile_unit == 2u ? (d >> 1) + (d >> 3) + (d >> 4) : d - (d >> 3); // quarters: x 11/16 of a pair's eight, x 7/8 of a tile's four
+	atomicAdd(sum, d ? d : 1u);
 }
 
 // Primary-ray grids.  MRT_CAMERA_DEBUG_GRID: RayTracerDebug::cast_debug_rays, src/godot/raytracer_debug.cpp:585-596
@@ -798,7 +824,8 @@ hipError_t launch_trace(const TraceParams &p_in, bool any_hit, bool count, hipSt
 	// (MRT_KERNEL_PACKET_DUAL) or 4 waves of one; every other kernel 4 waves of one tile
 	p.tile_group = (p.kernel == MRT_KERNEL_PACKET_DUAL && p.row_array != nullptr) ? 2u * ((p.rows_wg == 64u ? 64u : (uint32_t)MRT_ROWS_WG_LARGE) / MRT_WAVE) : MRT_WG / MRT_WAVE;
 	uint64_t threads;
-	if (p.lane_map == MAP_TILE8X8) {
+	if (p.tile_sched != nullptr && p.sched_hdr != nullptr && p.n_slots_max != 0u) threads = (uint64_t)p.n_slots_max * p.tile_unit * 64u; // (slots past sched_hdr[2] have nothing to do)
+	else if (p.lane_map == MAP_TILE8X8) {
 		const uint32_t th = 64u >> p.tile_w_log2;
 		threads = (uint64_t)p.tiles_x * ((p.rows + th - 1u) / th) * 64u;
 	} else threads = p.count;

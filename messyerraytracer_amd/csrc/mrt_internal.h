@@ -134,9 +134,16 @@ struct TraceParams {
 	// Frame-coherent tile schedule of grid casts (api.hip, TileSchedule): launch slot u runs schedule unit tile_sched[u]
 	// (a unit = tile_unit consecutive tiles: 1, or 2 for the 128-ray walk) and leaves the shader cycles it took in
 	// tile_cost[unit]; the next cast of the same grid launches the units longest first.  Both may be null.
+	// An entry of tile_sched: bits 0-27 an id, bits 28-31 what the slot's wave works on -- 0: schedule unit `id`; 1: the one tile
+	// `id` (in the wave's first group; a second group stays empty); 2 + q: quarter q of tile `id`, 4x4 pixels in lanes 0..15.
+	// The most expensive units of the last measured frame are launched in such pieces (api.hip schedule_split): a frame of a
+	// million rays ends with its longest walk, and the longest one is 2-3 x the 99th percentile.  sched_hdr[2] = slots in use
+	// (the launch covers n_slots_max); a piece parks its start time in tile_cost[n_units + slot] and ADDS its share to its unit.
 	const uint32_t *tile_sched;
 	uint32_t *tile_cost;
 	uint32_t tile_unit, n_units;
+	const uint32_t *sched_hdr;
+	uint32_t n_slots_max;
 	uint32_t kernel;           // MRT_KERNEL_LANE / MRT_KERNEL_PACKET
 	uint32_t stack_depth;      // LDS stack entries per lane
 	uint32_t xcd_swizzle;      // 1: remap blockIdx so each XCD owns a contiguous band

@@ -214,37 +214,47 @@ def test_packet_frustum_culling_skips_no_hit(built, cull):
 
 
 @pytest.mark.parametrize("kernel", [capi.KERNEL_AUTO, capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL])
-def test_frame_coherent_tile_schedule_changes_no_record(built, kernel):
-    """Grid casts of 2^15 .. 2^23 rays launch their tiles longest first by what each cost in the previous cast of the same grid
-    (mrt_options.tile_schedule, api.hip schedule_grid): any launch order gives the same records.  The same grid four times
-    (plain order, then three scheduled frames), another camera on the same grid (the old order is reused: still only a
-    permutation), a row block, a clipped grid, any-hit, tokens; and the same with the schedule off."""
+def test_frame_coherent_tile_schedule_changes_no_record(built, kernel, monkeypatch):
+    """Grid casts of 2^19 .. 2^24 rays (here from 2^15: MRT_SCHEDULE_MIN_LOG2) launch their tiles longest first by what each cost
+    in the previous cast of the same grid, the most expensive units in pieces -- quarter tiles in 16 lanes -- (mrt_options.
+    tile_schedule, api.hip schedule_grid / schedule_plan_kernel; here the top 5 % instead of the top 1 %: MRT_SCHED_SPLIT_PCT):
+    any launch order and any cut into pieces gives the same records.  The same grid sixteen times (through the kernel tuner's
+    twelve measuring frames with MRT_KERNEL_AUTO), another camera on the same grid (the old order is reused: still only a
+    permutation), a row block, a clipped grid, any-hit, tokens, a batch whose width the device finds; with pieces, without,
+    and with the schedule off."""
+    monkeypatch.setenv("MRT_SCHEDULE_MIN_LOG2", "15")
+    monkeypatch.setenv("MRT_SCHED_SPLIT_PCT", "5")
     v = synth.soup(20000, 0.25, 33)
     scene, osc = capi.Scene(v), po.OracleScene(v)
-    for off in (0, 1):
-        c = capi.Context(0, kernel=kernel, tile_schedule=off)
+    for sched in (0, 2, 1):
+        c = capi.Context(0, kernel=kernel, tile_schedule=sched)
         scene.upload(c)
         for (w, h) in ((512, 256), (333, 201)):
             cam = capi.camera_look((0, 0, -12), (0, 0, 1), w, h, 50.0)
-            want = osc.trace(po.grid_rays((0, 0, -12), (0, 0, 1), w, h, 50.0))
-            for frame in range(4):
-                parity.assert_exact(c.cast_grid(cam, w, h), want, f"kernel {kernel} schedule off={off} {w}x{h} frame {frame}")
+            rays = po.grid_rays((0, 0, -12), (0, 0, 1), w, h, 50.0)
+            want = osc.trace(rays)
+            for frame in range(16 if sched == 0 else 4):
+                parity.assert_exact(c.cast_grid(cam, w, h), want, f"kernel {kernel} schedule {sched} {w}x{h} frame {frame}")
             cam2 = capi.camera_look((3, 1, -11), (-0.2, 0, 1), w, h, 40.0)
             parity.assert_exact(c.cast_grid(cam2, w, h), osc.trace(po.grid_rays((3, 1, -11), (-0.2, 0, 1), w, h, 40.0)), "another camera, the old order")
-            for frame in range(2):
+            for frame in range(3):
                 parity.assert_exact(c.cast_grid(cam, w, h, y0=8, y1=h - 3), want[8 * w:(h - 3) * w], f"row block frame {frame}")
                 b = c.cast_grid(cam, w, h, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT)
                 assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
                 tok = c.cast_grid(cam, w, h, flags=capi.FLAG_TOKEN_OUT)
                 assert np.array_equal(tok != capi.TOKEN_MISS, want["prim_id"] >= 0)
+            if w % 8 == 0:
+                for frame in range(4):   # the width found on the device: scheduled from what the previous cast of as many rays found
+                    parity.assert_exact(c.cast(rays, flags=capi.FLAG_COHERENT), want, f"mrt_cast(COHERENT) frame {frame}")
         c.close()
 
 
 @pytest.mark.parametrize("wh", [(1280, 960), (1920, 1080)])
 def test_renderer_resolutions_on_the_c3_scene(built, wh):
-    """The reference's own workload size (1280x960: ROADMAP.md:175-181) and 1080p on the 1 M-triangle C3 scene: ten frames of
-    the same grid -- the measuring frames of both packet kernels, the frames launched in a measured tile order, the kernel
-    the library settles on -- every record of every frame against the oracle."""
+    """The reference's own workload size (1280x960: ROADMAP.md:175-181) and 1080p on the 1 M-triangle C3 scene: fifteen frames of
+    the same grid -- the twelve measuring frames of the kernel tuner (the 64-ray kernel, the 128-ray walk with its most expensive
+    units in pieces, the 128-ray walk whole), the frames launched in a measured tile order, what the library settles on -- every
+    record of every frame against the oracle."""
     w, h = wh
     cfg = synth.CONFIGS["C3"]
     verts = synth.scene_vertices(cfg)
@@ -255,7 +265,7 @@ def test_renderer_resolutions_on_the_c3_scene(built, wh):
     d_hits = c.device_alloc(w * h * 32)
     seen = set()
     got = np.zeros(w * h, dtype=T.HIT32)
-    for frame in range(10):
+    for frame in range(15):
         c.cast_grid(cam, w, h, hits=d_hits, flags=capi.FLAG_HITS_ON_DEVICE)
         seen.add(c.last_kernel_variant())
         c.d2h(got, d_hits)
