@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--copies", type=int, default=1)
     ap.add_argument("--lane", action="store_true", help="one lane per ray instead of the packet form")
     ap.add_argument("--device-blas", action="store_true", help="build the meshes' BVHs on the device")
+    ap.add_argument("--sah", action="store_true", help="with --device-blas: the binned-SAH form of the device builder (MRT_BUILD_SAH)")
     a = ap.parse_args()
     cfg = synth.CONFIGS["C5"]
     local, inst = synth.multi_mesh_instances(cfg["n_meshes"], cfg["tris_per_mesh"], cfg["s"], cfg["seed"])
@@ -37,7 +38,7 @@ def main():
         inst = np.concatenate(reps)
     c = capi.Context(0, kernel=capi.KERNEL_LANE if a.lane else capi.KERNEL_AUTO)
     t0 = time.perf_counter()
-    c.upload_two_level_scene(local, inst, blas_on_device=a.device_blas)
+    c.upload_two_level_scene(local, inst, blas_on_device=a.device_blas, sah=a.sah and a.device_blas)
     t_up = time.perf_counter() - t0
     info = c.scene_info()
     w = h = a.grid
@@ -54,7 +55,7 @@ def main():
     t0 = time.perf_counter()
     c.update_instances(inst)
     t_refit = time.perf_counter() - t0
-    out = dict(kernel="lane" if a.lane else "packet", blas="device LBVH" if a.device_blas else "host SAH", build_ms=c.stats()["last_build_ms"], instances=int(inst.shape[0]), mesh_tris=int(local.shape[0]), flat_tris=int(inst["n_tris"].sum()), info=info,
+    out = dict(kernel="lane" if a.lane else "packet", blas=("device SAH" if a.sah else "device LBVH") if a.device_blas else "host SAH", build_ms=c.stats()["last_build_ms"], instances=int(inst.shape[0]), mesh_tris=int(local.shape[0]), flat_tris=int(inst["n_tris"].sum()), info=info,
                upload_s=t_up, grid=[w, h], cast_grid_ms=ms, mrays=w * h / ms / 1e3, anyhit_ms=ms_any, anyhit_mrays=w * h / ms_any / 1e3,
                update_instances_ms=t_refit * 1e3)
     print(json.dumps(out))
