@@ -92,7 +92,7 @@ def test_options_are_validated_before_a_device_is_asked_for(built):
             capi.Context(0, kernel=capi.KERNEL_PACKET_QUAD)
         assert e.value.status == capi.ERR_UNSUPPORTED
     with pytest.raises(capi.MrtError) as e:
-        capi.Context(0, tile_schedule=2)
+        capi.Context(0, tile_schedule=3)     # 0 = longest first with pieces, 1 = plain order, 2 = longest first without pieces
     assert e.value.status == capi.ERR_INVALID
 
 
