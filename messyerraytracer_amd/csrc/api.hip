@@ -221,6 +221,8 @@ uint32_t pick_kernel(const mrt_ctx *ctx, bool coherent, uint64_t count)
 	// 1 M-triangle scene, the longer the wider its 8x8 tile opens), and a small batch is over when its slowest wave is.
 	// Coherent grids on the C3 scene (tools/bench_small_batches.py, profiles/r02d_small_batches.txt): 64^2 rays 0.69 ms by
 	// packets, 0.32 ms one lane per ray; 128^2 0.56 / 0.40; 256^2 0.40 / 0.43; 512^2 0.35 / 0.59 (C2 scene: even at 128^2).
+	// (Batches whose tiling is known or found -- grids, tiled casts, mrt_cast(COHERENT) -- leave this rule from 2^11 rays on:
+	// quarter_small_grid() runs them by packets of 16 rays, faster than either.)
 	const bool few = ctx->opts.kernel == MRT_KERNEL_AUTO && count < (1ull << 15);
 	if (ctx->two_level) return coherent && !few && ctx->opts.kernel != MRT_KERNEL_LANE ? mrt::MRT_KERNEL_TWO_LEVEL_PACKET : mrt::MRT_KERNEL_TWO_LEVEL;
 	if (ctx->opts.kernel == MRT_KERNEL_PACKET_DUAL || ctx->opts.kernel == MRT_KERNEL_PACKET_ROWS)
@@ -293,6 +295,8 @@ constexpr int kTuneFrames = 4; // frames per candidate of the grid kernel tuner 
 static bool schedule_applies(const mrt_ctx *ctx, const mrt::TraceParams &p);
 static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p);
 static int schedule_sort(mrt_ctx *ctx);
+constexpr uint64_t kQuarterMinRays = 1ull << 11, kQuarterMaxTiles = 3600; // small grids in quarter tiles: see quarter_small_grid()
+static void quarter_small_grid(const mrt_ctx *ctx, mrt::TraceParams &p);
 namespace {
 
 // Lane kernel launch: plain (one fixed ray per lane) or persistent (resident waves pulling rays
@@ -390,6 +394,12 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 		HIP_TRY(ctx, mrt::launch_detect_grid(d_rays, p.in_fmt, count, p.tile_w_log2, ctx->d_counters + mrt::kDetectScratchOff, d_auto, ctx->d_auto_host, ctx->stream));
 		p.lane_map = mrt::MAP_AUTO; p.auto_grid = d_auto;
 	}
+	// a small batch whose width the device finds: quarter tiles (quarter_small_grid; if no width is found the lanes stay linear and
+	// three of four waves have nothing to do).  From 2^12 rays: the packets then beat one lane per ray (64^2: 0.26 against 0.31 ms)
+	if (detect && ctx->opts.kernel == MRT_KERNEL_AUTO && !ctx->two_level && !ctx->opts.count_visits && p.tile_w_log2 == 3u && p.n_nodes < mrt::kAsmNodeLimit &&
+			count >= kQuarterMinRays && count <= kQuarterMaxTiles * 64u && (p.kernel == MRT_KERNEL_PACKET_ASM || p.kernel == MRT_KERNEL_LANE)) {
+		p.kernel = MRT_KERNEL_PACKET_ASM; p.quarter_all = 1u;
+	}
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));
 	const bool any = mode == MRT_MODE_ANY_HIT;
 	// the tile schedule for a batch whose width the device finds: sized from what the previous cast of as many rays found
@@ -412,7 +422,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 		const uint32_t packet_kernel = p.kernel;
 		char packet_variant[96]; std::snprintf(packet_variant, sizeof(packet_variant), "%s", mrt::last_trace_variant());
 		mrt::TraceParams lp = p;
-		lp.kernel = MRT_KERNEL_LANE; lp.lane_map = mrt::MAP_LINEAR; lp.auto_grid = nullptr; lp.skip_when = 0u;
+		lp.kernel = MRT_KERNEL_LANE; lp.lane_map = mrt::MAP_LINEAR; lp.auto_grid = nullptr; lp.skip_when = 0u; lp.quarter_all = 0u;
 		if ((rc = launch_lane(ctx, lp, count, any, count >= 65536))) return rc; // (a two-level scene: its own lane kernels)
 		ctx->queued_alt_kernel = ctx->queued_kernel; // what launch_lane queued: runs if the batch is judged incoherent
 		std::snprintf(ctx->queued_alt_variant, sizeof(ctx->queued_alt_variant), "%s", ctx->queued_variant);
@@ -1263,6 +1273,21 @@ static int schedule_sort(mrt_ctx *ctx)
 	return MRT_OK;
 }
 
+// Small grids of known width (mrt_cast_grid, mrt_cast_tiled; flat scenes, MRT_KERNEL_AUTO): from 2^11 rays up to 3 600 tiles the 64-ray
+// packet kernel with EVERY tile launched as its four quarter tiles (TraceParams::quarter_all).  Such a grid has fewer tiles than the
+// device has wave slots (8 192), so it lasts as long as its longest walk whatever the order, and a 16-ray quarter tile's walk is
+// about half as long as its tile's.  C3 scene, kernel time (whole tiles by packets / one lane per ray / quarter tiles): 64^2 0.67 /
+// 0.31 / 0.26 ms, 128^2 0.53 / 0.37 / 0.20, 256^2 0.37 / 0.40 / 0.24, 384^2 0.34 / 0.47 / 0.25, 640x360 0.38 / 0.55 / 0.29; from
+// 4 096 tiles on (512^2: 0.32 / 0.55 / 0.32) four times as many waves are two rounds of them and nothing is gained; below 2^11 rays
+// one lane per ray is the shortest (32^2: 1.22 / 0.34 / 0.36).  The C2 scene draws the same lines (128^2 0.26 / 0.27 / 0.11).
+static void quarter_small_grid(const mrt_ctx *ctx, mrt::TraceParams &p)
+{
+	if (ctx->opts.kernel != MRT_KERNEL_AUTO || ctx->two_level || ctx->opts.count_visits || p.lane_map != mrt::MAP_TILE8X8 || p.tile_w_log2 != 3u) return;
+	if (p.n_nodes >= mrt::kAsmNodeLimit || p.count < kQuarterMinRays) return;
+	if ((uint64_t)p.tiles_x * ((p.rows + 7u) / 8u) > kQuarterMaxTiles) return;
+	p.kernel = MRT_KERNEL_PACKET_ASM; p.quarter_all = 1u;
+}
+
 // The kernel of a mid-size grid cast, by measurement (mrt_ctx::GridTune).  Only for MRT_KERNEL_AUTO on flat scenes, blocking
 // casts (a timing is needed), grids the schedule applies to.
 static void tune_grid_kernel(mrt_ctx *ctx, mrt::TraceParams &p, int mode, uint32_t flags)
@@ -1271,7 +1296,7 @@ static void tune_grid_kernel(mrt_ctx *ctx, mrt::TraceParams &p, int mode, uint32
 	t.armed = false; t.no_pieces = false;
 	if (ctx->opts.kernel != MRT_KERNEL_AUTO || ctx->two_level || !ctx->d_rows || ctx->opts.count_visits || ctx->opts.tile_schedule == 1u) return;
 	// (from 2^22 rays on the 128-ray walk won every measurement -- 2560x1440 .. 7680x4320, C5's row blocks --: no frames are spent on the other one)
-	if (p.lane_map != mrt::MAP_TILE8X8 || p.count < kScheduleMinRays || p.count >= kScheduleMaxRays || p.count >= (1ull << 22)) return;
+	if (p.lane_map != mrt::MAP_TILE8X8 || p.quarter_all || p.count < kScheduleMinRays || p.count >= kScheduleMaxRays || p.count >= (1ull << 22)) return;
 	if (p.kernel != MRT_KERNEL_PACKET_ASM && p.kernel != MRT_KERNEL_PACKET_DUAL) return;
 	const bool same = t.grid_w == p.grid_w && t.grid_h == p.grid_h && t.y0 == p.y0 && t.rows == p.rows && t.mode == mode;
 	if (!same) { t.grid_w = p.grid_w; t.grid_h = p.grid_h; t.y0 = p.y0; t.rows = p.rows; t.mode = mode; t.phase = 0; t.t_asm = t.t_dual = t.t_whole = 0.0f; }
@@ -1351,8 +1376,9 @@ int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t
 	p.out_fmt = out_format(ctx, flags, mode);
 	p.lane_map = ctx->opts.grid_tile == 1 ? mrt::MAP_LINEAR : mrt::MAP_TILE8X8;
 	p.kernel = pick_kernel(ctx, true, p.count);
+	quarter_small_grid(ctx, p);
 	tune_grid_kernel(ctx, p, mode, flags);
-	const bool scheduled = schedule_applies(ctx, p);
+	const bool scheduled = !p.quarter_all && schedule_applies(ctx, p);
 	if (scheduled && (rc = schedule_grid(ctx, p))) return rc;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));
@@ -1389,6 +1415,7 @@ int mrt_cast_tiled(mrt_ctx *ctx, const mrt_ray32 *d_rays, mrt_hit32 *d_hits,
 	p.kernel = pick_kernel(ctx, true, p.count);
 	p.grid_w = grid_w; p.grid_h = rows; p.y0 = 0; p.rows = rows;
 	p.tiles_x = (grid_w + (1u << p.tile_w_log2) - 1u) >> p.tile_w_log2;
+	quarter_small_grid(ctx, p);
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));
 	HIP_TRY(ctx, mrt::launch_trace(p, mode == MRT_MODE_ANY_HIT, ctx->opts.count_visits != 0, ctx->stream));

@@ -98,7 +98,8 @@ __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t 
 		// the schedule of the previous frame: launch slot -> unit of tile_unit consecutive tiles.  Only if it is a schedule
 		// of THIS grid (a batch whose row width is found on the device, MAP_AUTO, was scheduled from the last cast's width)
 		uint32_t quarter = 4u; // 0..3: the slot's wave works on that 4x4 quarter of its tile, in lanes 0..15
-		if (p.tile_sched != nullptr && ((uint64_t)tiles_x * tiles_y + p.tile_unit - 1u) / p.tile_unit == p.n_units) {
+		if (p.quarter_all) { quarter = (uint32_t)tile & 3u; tile >>= 2; if (l >= 16u || tile >= (uint64_t)tiles_x * tiles_y) return false; }
+		else if (p.tile_sched != nullptr && ((uint64_t)tiles_x * tiles_y + p.tile_unit - 1u) / p.tile_unit == p.n_units) {
 			const uint64_t slot = tile / p.tile_unit;
 			if (slot >= (p.sched_hdr ? p.sched_hdr[2] : p.n_units)) return false;
 			const uint32_t e = p.tile_sched[slot], what = e >> 28, id = e & 0x0FFFFFFFu;
@@ -827,8 +828,8 @@ hipError_t launch_trace(const TraceParams &p_in, bool any_hit, bool count, hipSt
 	if (p.tile_sched != nullptr && p.sched_hdr != nullptr && p.n_slots_max != 0u) threads = (uint64_t)p.n_slots_max * p.tile_unit * 64u; // (slots past sched_hdr[2] have nothing to do)
 	else if (p.lane_map == MAP_TILE8X8) {
 		const uint32_t th = 64u >> p.tile_w_log2;
-		threads = (uint64_t)p.tiles_x * ((p.rows + th - 1u) / th) * 64u;
-	} else threads = p.count;
+		threads = (uint64_t)p.tiles_x * ((p.rows + th - 1u) / th) * 64u * (p.quarter_all ? 4u : 1u);
+	} else threads = p.count * ((p.lane_map == MAP_AUTO && p.quarter_all) ? 4u : 1u); // (a width found on the device: whole tiles, count / 64 of them)
 	if (threads == 0) return hipSuccess;
 	const uint64_t blocks = (threads + MRT_WG - 1) / MRT_WG;
 	if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;

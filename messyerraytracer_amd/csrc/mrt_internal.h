@@ -144,6 +144,10 @@ struct TraceParams {
 	uint32_t tile_unit, n_units;
 	const uint32_t *sched_hdr;
 	uint32_t n_slots_max;
+	// Small grids (api.hip quarter_small_grid): EVERY tile is launched as its four quarter tiles (launch slot s = quarter s & 3 of
+	// tile s >> 2, 16 rays in lanes 0..15) -- a grid of fewer tiles than the device has wave slots lasts as long as its longest
+	// walk, and a quarter tile's walk is about half as long as its tile's.
+	uint32_t quarter_all;
 	uint32_t kernel;           // MRT_KERNEL_LANE / MRT_KERNEL_PACKET
 	uint32_t stack_depth;      // LDS stack entries per lane
 	uint32_t xcd_swizzle;      // 1: remap blockIdx so each XCD owns a contiguous band

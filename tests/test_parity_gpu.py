@@ -249,6 +249,44 @@ def test_frame_coherent_tile_schedule_changes_no_record(built, kernel, monkeypat
         c.close()
 
 
+def test_small_grids_in_quarter_tiles(built):
+    """Grids of 2^11 rays up to 3 600 tiles are cast by the packet kernel with every tile launched as its four quarter tiles
+    (16 rays in lanes 0..15 of a wave; api.hip quarter_small_grid): a grid of fewer tiles than the device has wave slots lasts
+    as long as its longest walk, and a quarter tile's walk is half as long.  Records are the oracle's at every size: widths and
+    heights that are no multiples of 8 or of 4 (clipped quarters, quarters wholly outside the grid), the fused grid cast, a row
+    block, rays read from memory with a declared width (mrt_cast_tiled) and with the width found on the device
+    (mrt_cast(COHERENT)), any-hit, tokens; below 2^11 rays and above 3 600 tiles the other kernels."""
+    v = synth.soup(20000, 0.25, 36)
+    scene, osc = capi.Scene(v), po.OracleScene(v)
+    c = capi.Context(0)
+    scene.upload(c)
+    for (w, h) in ((16, 12), (32, 32), (64, 40), (100, 70), (101, 67), (130, 61), (256, 256), (321, 243), (640, 360), (648, 368)):
+        cam = capi.camera_look((0, 0, -12), (0, 0.05, 1), w, h, 50.0)
+        rays = po.grid_rays((0, 0, -12), (0, 0.05, 1), w, h, 50.0)
+        want = osc.trace(rays)
+        parity.assert_exact(c.cast_grid(cam, w, h), want, f"{w}x{h} cast_grid")
+        tiles = ((w + 7) // 8) * ((h + 7) // 8)
+        quartered = w * h >= 2048 and tiles <= 3600
+        assert c.last_kernel_variant().startswith("trace_packet_asm_kernel" if quartered else ("trace_lane_kernel" if w * h < 2048 else "trace_packet_")), (w, h, c.last_kernel_variant())
+        parity.assert_exact(c.cast_grid(cam, w, h, y0=3, y1=h - 2), want[3 * w:(h - 2) * w], f"{w}x{h} row block")
+        b = c.cast_grid(cam, w, h, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT)
+        assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
+        tok = c.cast_grid(cam, w, h, flags=capi.FLAG_TOKEN_OUT)
+        assert np.array_equal(tok != capi.TOKEN_MISS, want["prim_id"] >= 0)
+        parity.assert_exact(c.cast(rays, flags=capi.FLAG_COHERENT), want, f"{w}x{h} mrt_cast(COHERENT)")
+        d_rays, d_hits = c.device_alloc(rays.nbytes), c.device_alloc(rays.shape[0] * 32)
+        c.h2d(d_rays, rays)
+        c.cast_tiled(d_rays, d_hits, w, h)
+        got = np.zeros(rays.shape[0], dtype=T.HIT32)
+        c.d2h(got, d_hits)
+        parity.assert_exact(got, want, f"{w}x{h} mrt_cast_tiled")
+        c.device_free(d_rays); c.device_free(d_hits)
+    inc = synth.incoherent_rays(256 * 64, 23)       # flagged coherent, but not: the device's verdict still routes it to the lane kernel
+    parity.assert_exact(c.cast(inc, flags=capi.FLAG_COHERENT), osc.trace(inc), "incoherent rays flagged coherent")
+    assert c.stats()["reserved"] == 1
+    c.close()
+
+
 @pytest.mark.parametrize("wh", [(1280, 960), (1920, 1080)])
 def test_renderer_resolutions_on_the_c3_scene(built, wh):
     """The reference's own workload size (1280x960: ROADMAP.md:175-181) and 1080p on the 1 M-triangle C3 scene: fifteen frames of
