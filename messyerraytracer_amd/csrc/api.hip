@@ -296,6 +296,7 @@ static bool schedule_applies(const mrt_ctx *ctx, const mrt::TraceParams &p);
 static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p);
 static int schedule_sort(mrt_ctx *ctx);
 constexpr uint64_t kQuarterMinRays = 1ull << 11, kQuarterMaxTiles = 3600; // small grids in quarter tiles: see quarter_small_grid()
+constexpr uint64_t kQuarterAllRays = 2048ull * 64ull; // up to here four quarters per tile still fit one round of waves: no schedule needed
 static void quarter_small_grid(const mrt_ctx *ctx, mrt::TraceParams &p);
 namespace {
 
@@ -404,7 +405,9 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	const bool any = mode == MRT_MODE_ANY_HIT;
 	// the tile schedule for a batch whose width the device finds: sized from what the previous cast of as many rays found
 	bool scheduled = false;
-	if (detect && !ctx->pending && ctx->last_detect_count == count && ctx->h_auto[0] != 0u && ctx->h_auto[3] == 0u && schedule_applies(ctx, p)) {
+	if (detect && !ctx->pending && ctx->last_detect_count == count && ctx->h_auto[0] != 0u && ctx->h_auto[3] == 0u && schedule_applies(ctx, p) &&
+			!(p.quarter_all && count <= kQuarterAllRays)) {
+		p.quarter_all = 0u;
 		mrt::TraceParams g = p;
 		g.grid_w = ctx->h_auto[0]; g.rows = ctx->h_auto[1]; g.grid_h = g.rows; g.y0 = 0; g.tiles_x = ctx->h_auto[2];
 		if ((rc = schedule_grid(ctx, g))) return rc;
@@ -1116,13 +1119,19 @@ int mrt_has_pending(const mrt_ctx *ctx) { return ctx && ctx->pending ? 1 : 0; }
 #define MRT_SCHEDULE_MAX_LOG2 24
 #endif
 constexpr uint64_t kScheduleMaxRays = 1ull << MRT_SCHEDULE_MAX_LOG2;
-// 2^19: 640x360 (2^17.8 rays) measured slower with it.  MRT_SCHEDULE_MIN_LOG2 lowers the bound (the tests schedule small grids)
+// From 2^17 rays (2 048 tiles: below, all tiles go in quarter tiles anyway, quarter_small_grid).  With the order alone 640x360
+// measured 7 % slower scheduled than not; with the most expensive tiles in quarter tiles until the chip is full
+// (schedule_plan_kernel) it is 20 % faster.  MRT_SCHEDULE_MIN_LOG2 moves the bound (the tests schedule smaller grids)
 static uint64_t schedule_min_rays()
 {
 	const char *e = std::getenv("MRT_SCHEDULE_MIN_LOG2"); // (read per cast: a test sets it for its own contexts)
-	const int k = e ? std::atoi(e) : 19;
-	return 1ull << (k >= 12 && k <= 24 ? k : 19);
+	const int k = e ? std::atoi(e) : 17;
+	return 1ull << (k >= 12 && k <= 24 ? k : 17);
 }
+// the grid tuner: from 2^19 rays on the 128-ray walk is a candidate (below, the 64-ray kernel won every measurement); a test that
+// moves the schedule's bound moves this one with it
+static uint64_t tune_min_rays() { return std::getenv("MRT_SCHEDULE_MIN_LOG2") ? schedule_min_rays() : (1ull << 19); }
+#define kTuneMinRays tune_min_rays()
 #define kScheduleMinRays schedule_min_rays()
 // The launch list of a generation: the sorted order, with the units whose cost says they would end the frame alone launched in
 // pieces (TraceParams::tile_sched).  A frame of 1-2 M rays is one or two rounds of waves, so it lasts as long as its longest
@@ -1155,6 +1164,11 @@ __global__ __launch_bounds__(1024) void schedule_plan_kernel(const uint32_t *cos
 	while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if ((unsigned long long)cost_sorted[mid] > thr) lo = mid + 1u; else hi = mid; }
 	const uint32_t per_quartered = unit == 2u ? 7u : 3u; // extra slots of a unit in quarters
 	uint32_t quartered = sum == 0ull ? 0u : lo;
+	// fewer units than wave slots: the frame is one round of waves and lasts as long as its longest walk; the most expensive units
+	// go in quarters until the round is full (C3 scene, 64-ray kernel: 512^2 0.305 -> 0.248 ms, 640x360 0.284 -> 0.227, 960x540
+	// 0.378 -> 0.309; filling to 1.25 or 1.5 rounds instead: 0.293 / 0.317 at 512^2)
+	if (sum != 0ull && n_units < kWaveSlots && (kWaveSlots - n_units) / per_quartered > quartered) quartered = (kWaveSlots - n_units) / per_quartered;
+	if (quartered > n_units) quartered = n_units;
 	if ((unsigned long long)quartered * per_quartered > n_extra) quartered = n_extra / per_quartered;
 	hdr[0] = quartered; hdr[1] = 0u; hdr[2] = n_units + quartered * per_quartered;
 }
@@ -1202,7 +1216,8 @@ static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p)
 	}
 	if (!same) {
 		HIP_TRY(ctx, hipStreamSynchronize(s.side)); // no sort of the old grid may still use the arrays
-		s.n_slots_max = pieces ? n_units + n_units / 2u : n_units; // at most half as many extra slots as there are units
+		// room for pieces: half as many extra slots as there are units, or what fills one round of waves (schedule_plan_kernel)
+		s.n_slots_max = pieces ? (n_units + n_units / 2u > kWaveSlots ? n_units + n_units / 2u : kWaveSlots) : n_units;
 		for (int k = 0; k < 2; k++)
 			if ((rc = ensure(ctx, s.cost[k], ((size_t)n_units + s.n_slots_max) * 4)) || (rc = ensure(ctx, s.order[k], (size_t)n_units * 4)) ||
 					(rc = ensure(ctx, s.slots[k], (size_t)s.n_slots_max * 4)) || (rc = ensure(ctx, s.hdr[k], 16))) return rc;
@@ -1296,7 +1311,7 @@ static void tune_grid_kernel(mrt_ctx *ctx, mrt::TraceParams &p, int mode, uint32
 	t.armed = false; t.no_pieces = false;
 	if (ctx->opts.kernel != MRT_KERNEL_AUTO || ctx->two_level || !ctx->d_rows || ctx->opts.count_visits || ctx->opts.tile_schedule == 1u) return;
 	// (from 2^22 rays on the 128-ray walk won every measurement -- 2560x1440 .. 7680x4320, C5's row blocks --: no frames are spent on the other one)
-	if (p.lane_map != mrt::MAP_TILE8X8 || p.quarter_all || p.count < kScheduleMinRays || p.count >= kScheduleMaxRays || p.count >= (1ull << 22)) return;
+	if (p.lane_map != mrt::MAP_TILE8X8 || p.quarter_all || p.count < kScheduleMinRays || p.count < kTuneMinRays || p.count >= kScheduleMaxRays || p.count >= (1ull << 22)) return;
 	if (p.kernel != MRT_KERNEL_PACKET_ASM && p.kernel != MRT_KERNEL_PACKET_DUAL) return;
 	const bool same = t.grid_w == p.grid_w && t.grid_h == p.grid_h && t.y0 == p.y0 && t.rows == p.rows && t.mode == mode;
 	if (!same) { t.grid_w = p.grid_w; t.grid_h = p.grid_h; t.y0 = p.y0; t.rows = p.rows; t.mode = mode; t.phase = 0; t.t_asm = t.t_dual = t.t_whole = 0.0f; }
@@ -1378,7 +1393,8 @@ int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t
 	p.kernel = pick_kernel(ctx, true, p.count);
 	quarter_small_grid(ctx, p);
 	tune_grid_kernel(ctx, p, mode, flags);
-	const bool scheduled = !p.quarter_all && schedule_applies(ctx, p);
+	const bool scheduled = schedule_applies(ctx, p) && !(p.quarter_all && p.count <= kQuarterAllRays);
+	if (scheduled) p.quarter_all = 0u; // (from 2 048 tiles on the cost history says WHICH tiles go in quarters)
 	if (scheduled && (rc = schedule_grid(ctx, p))) return rc;
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));

@@ -218,10 +218,11 @@ def test_frame_coherent_tile_schedule_changes_no_record(built, kernel, monkeypat
     """Grid casts of 2^19 .. 2^24 rays (here from 2^15: MRT_SCHEDULE_MIN_LOG2) launch their tiles longest first by what each cost
     in the previous cast of the same grid, the most expensive units in pieces -- quarter tiles in 16 lanes -- (mrt_options.
     tile_schedule, api.hip schedule_grid / schedule_plan_kernel; here the top 5 % instead of the top 1 %: MRT_SCHED_SPLIT_PCT):
-    any launch order and any cut into pieces gives the same records.  The same grid sixteen times (through the kernel tuner's
-    twelve measuring frames with MRT_KERNEL_AUTO), another camera on the same grid (the old order is reused: still only a
-    permutation), a row block, a clipped grid, any-hit, tokens, a batch whose width the device finds; with pieces, without,
-    and with the schedule off."""
+    any launch order and any cut into pieces gives the same records.  The same grid sixteen times, another camera on the same grid
+    (the old order is reused: still only a permutation), a row block, a clipped grid, any-hit, tokens, a batch whose width the device
+    finds; with pieces, without, and with the schedule off.  (With MRT_KERNEL_AUTO grids of this size are not scheduled: every tile
+    goes in quarter tiles, test_small_grids_in_quarter_tiles; the explicit kernels are what is scheduled here, and
+    test_renderer_resolutions_on_the_c3_scene runs the tuner on grids of its own size.)"""
     monkeypatch.setenv("MRT_SCHEDULE_MIN_LOG2", "15")
     monkeypatch.setenv("MRT_SCHED_SPLIT_PCT", "5")
     v = synth.soup(20000, 0.25, 33)
