@@ -151,7 +151,8 @@ typedef struct mrt_stats {
 	uint32_t max_stack_depth;    /* count_visits only                           */
 	uint64_t dead_pops;          /* count_visits, packet kernel: popped nodes no lane still needed */
 	uint32_t detected_grid_w;    /* count_visits: row width found for the last coherent mrt_cast (0 = none) */
-	uint32_t reserved;           /* count_visits: 1 if the last batch declared coherent was judged incoherent on the device */
+	uint32_t reserved;           /* 1 if the last batch declared coherent went to the one-lane-per-ray kernel by the device's verdict:
+	                                judged incoherent, or fewer than 2^15 rays in which no row width was found */
 	float last_build_ms;         /* device time of the last mrt_build_scene_device */
 	uint32_t last_kernel;        /* MRT_KERNEL_* that did the work of the last blocking cast (a batch declared coherent is
 	                                checked on the device: this is the kernel the device chose); 0 after an ASYNC cast */

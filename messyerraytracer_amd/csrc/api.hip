@@ -295,7 +295,7 @@ constexpr int kTuneFrames = 4; // frames per candidate of the grid kernel tuner 
 static bool schedule_applies(const mrt_ctx *ctx, const mrt::TraceParams &p);
 static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p);
 static int schedule_sort(mrt_ctx *ctx);
-constexpr uint64_t kQuarterMinRays = 1ull << 11, kQuarterMaxTiles = 3600; // small grids in quarter tiles: see quarter_small_grid()
+constexpr uint64_t kQuarterMinRays = 64, kQuarterMaxTiles = 3600, kSixteenthMaxTiles = 512; // small grids in quarter / sixteenth tiles: see quarter_small_grid()
 constexpr uint64_t kQuarterAllRays = 2048ull * 64ull; // up to here four quarters per tile still fit one round of waves: no schedule needed
 static void quarter_small_grid(const mrt_ctx *ctx, mrt::TraceParams &p);
 namespace {
@@ -389,17 +389,17 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	// Timed with the sort as pre-processing (last_sort_ms); last_trace_ms is the trace kernel alone.
 	const bool persistent_kind = p.kernel == MRT_KERNEL_LANE_PERSISTENT || p.kernel == MRT_KERNEL_LANE4_PERSISTENT ||
 			p.kernel == MRT_KERNEL_LANE8_PERSISTENT;
-	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 4096 && ctx->opts.grid_tile != 1 && !persistent_kind;
+	const bool detect = !sort && (flags & MRT_FLAG_COHERENT) && count >= 256 && ctx->opts.grid_tile != 1 && !persistent_kind;
 	if (detect) {
 		uint32_t *d_auto = reinterpret_cast<uint32_t *>(ctx->d_counters + mrt::kAutoGridOff);
 		HIP_TRY(ctx, mrt::launch_detect_grid(d_rays, p.in_fmt, count, p.tile_w_log2, ctx->d_counters + mrt::kDetectScratchOff, d_auto, ctx->d_auto_host, ctx->stream));
 		p.lane_map = mrt::MAP_AUTO; p.auto_grid = d_auto;
 	}
-	// a small batch whose width the device finds: quarter tiles (quarter_small_grid; if no width is found the lanes stay linear and
-	// three of four waves have nothing to do).  From 2^12 rays: the packets then beat one lane per ray (64^2: 0.26 against 0.31 ms)
+	// a small batch whose width the device finds: sixteenth or quarter tiles (quarter_small_grid; if no width is found the lanes stay
+	// linear and the waves past the batch have nothing to do)
 	if (detect && ctx->opts.kernel == MRT_KERNEL_AUTO && !ctx->two_level && !ctx->opts.count_visits && p.tile_w_log2 == 3u && p.n_nodes < mrt::kAsmNodeLimit &&
 			count >= kQuarterMinRays && count <= kQuarterMaxTiles * 64u && (p.kernel == MRT_KERNEL_PACKET_ASM || p.kernel == MRT_KERNEL_LANE)) {
-		p.kernel = MRT_KERNEL_PACKET_ASM; p.quarter_all = 1u;
+		p.kernel = MRT_KERNEL_PACKET_ASM; p.quarter_all = count <= kSixteenthMaxTiles * 64u ? 2u : 1u;
 	}
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));
 	const bool any = mode == MRT_MODE_ANY_HIT;
@@ -1288,19 +1288,23 @@ static int schedule_sort(mrt_ctx *ctx)
 	return MRT_OK;
 }
 
-// Small grids of known width (mrt_cast_grid, mrt_cast_tiled; flat scenes, MRT_KERNEL_AUTO): from 2^11 rays up to 3 600 tiles the 64-ray
-// packet kernel with EVERY tile launched as its four quarter tiles (TraceParams::quarter_all).  Such a grid has fewer tiles than the
-// device has wave slots (8 192), so it lasts as long as its longest walk whatever the order, and a 16-ray quarter tile's walk is
-// about half as long as its tile's.  C3 scene, kernel time (whole tiles by packets / one lane per ray / quarter tiles): 64^2 0.67 /
-// 0.31 / 0.26 ms, 128^2 0.53 / 0.37 / 0.20, 256^2 0.37 / 0.40 / 0.24, 384^2 0.34 / 0.47 / 0.25, 640x360 0.38 / 0.55 / 0.29; from
-// 4 096 tiles on (512^2: 0.32 / 0.55 / 0.32) four times as many waves are two rounds of them and nothing is gained; below 2^11 rays
-// one lane per ray is the shortest (32^2: 1.22 / 0.34 / 0.36).  The C2 scene draws the same lines (128^2 0.26 / 0.27 / 0.11).
+// Small grids of known width (mrt_cast_grid, mrt_cast_tiled; flat scenes, MRT_KERNEL_AUTO; mrt_cast(COHERENT) does the same for a
+// width found on the device): the 64-ray packet kernel with EVERY tile launched in pieces (TraceParams::quarter_all) -- up to 512
+// tiles as its sixteen 2x2-pixel sixteenths (4 rays in lanes 0..3 of a wave), up to 3 600 tiles as its four 4x4-pixel quarters (16
+// rays).  Such a grid has fewer tiles than the device has wave slots (8 192), so it lasts as long as its longest walk whatever the
+// order, and a walk for 16 rays is about half as long as its tile's, one for 4 rays a third.  C3 scene, kernel time in ms (whole
+// tiles by packets / one lane per ray / quarters / sixteenths): 16x12 - / 0.23 / - / 0.15, 32^2 1.22 / 0.34 / 0.36 / 0.15, 64^2 0.67 /
+// 0.31 / 0.26 / 0.12, 128^2 0.53 / 0.37 / 0.20 / 0.18, 192^2 0.46 / 0.45 / 0.25 / 0.22, 256^2 0.37 / 0.40 / 0.24 / 0.25, 384^2 0.34 / 0.47 /
+// 0.25, 640x360 0.38 / 0.55 / 0.29; sixteen times as many waves are two rounds of them from 1 024 tiles on, four times as many from
+// 4 096 (512^2: 0.32 / 0.55 / 0.32), and nothing is gained.  The C2 scene draws the same lines (64^2 0.38 / 0.27 / 0.18 / 0.09;
+// 192^2 - / - / 0.10 / 0.10; 256^2 - / - / 0.09 / 0.15).  Between 2 048 and 8 192 tiles the cost history picks the tiles (schedule_plan_kernel).
 static void quarter_small_grid(const mrt_ctx *ctx, mrt::TraceParams &p)
 {
 	if (ctx->opts.kernel != MRT_KERNEL_AUTO || ctx->two_level || ctx->opts.count_visits || p.lane_map != mrt::MAP_TILE8X8 || p.tile_w_log2 != 3u) return;
 	if (p.n_nodes >= mrt::kAsmNodeLimit || p.count < kQuarterMinRays) return;
 	if ((uint64_t)p.tiles_x * ((p.rows + 7u) / 8u) > kQuarterMaxTiles) return;
-	p.kernel = MRT_KERNEL_PACKET_ASM; p.quarter_all = 1u;
+	p.kernel = MRT_KERNEL_PACKET_ASM;
+	p.quarter_all = (uint64_t)p.tiles_x * ((p.rows + 7u) / 8u) <= kSixteenthMaxTiles ? 2u : 1u;
 }
 
 // The kernel of a mid-size grid cast, by measurement (mrt_ctx::GridTune).  Only for MRT_KERNEL_AUTO on flat scenes, blocking

@@ -98,7 +98,9 @@ __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t 
 		// the schedule of the previous frame: launch slot -> unit of tile_unit consecutive tiles.  Only if it is a schedule
 		// of THIS grid (a batch whose row width is found on the device, MAP_AUTO, was scheduled from the last cast's width)
 		uint32_t quarter = 4u; // 0..3: the slot's wave works on that 4x4 quarter of its tile, in lanes 0..15
-		if (p.quarter_all) { quarter = (uint32_t)tile & 3u; tile >>= 2; if (l >= 16u || tile >= (uint64_t)tiles_x * tiles_y) return false; }
+		uint32_t sixteenth = 16u; // 0..15 (quarter_all == 2): on that 2x2 sixteenth of its tile, in lanes 0..3
+		if (p.quarter_all == 2u) { sixteenth = (uint32_t)tile & 15u; tile >>= 4; if (l >= 4u || tile >= (uint64_t)tiles_x * tiles_y) return false; }
+		else if (p.quarter_all) { quarter = (uint32_t)tile & 3u; tile >>= 2; if (l >= 16u || tile >= (uint64_t)tiles_x * tiles_y) return false; }
 		else if (p.tile_sched != nullptr && ((uint64_t)tiles_x * tiles_y + p.tile_unit - 1u) / p.tile_unit == p.n_units) {
 			const uint64_t slot = tile / p.tile_unit;
 			if (slot >= (p.sched_hdr ? p.sched_hdr[2] : p.n_units)) return false;
@@ -129,7 +131,10 @@ __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t 
 			tx = (stx << 5) + mx; ty = (sty << 5) + my;
 		} else if (p.tile_order == 3u && xcd_strips(p, tile, tiles_x, tiles_y, tx, ty)) {
 		} else { tx = (uint32_t)(tile % tiles_x); ty = (uint32_t)(tile / tiles_x); }
-		if (quarter < 4u) { // (schedule pieces exist for 8x8 tiles only: k == 3)
+		if (sixteenth < 16u) {
+			px = (tx << 3) + ((sixteenth & 3u) << 1) + (l & 1u);
+			py = (ty << 3) + ((sixteenth >> 2) << 1) + (l >> 1);
+		} else if (quarter < 4u) { // (schedule pieces exist for 8x8 tiles only: k == 3)
 			px = (tx << 3) + ((quarter & 1u) << 2) + (l & 3u);
 			py = (ty << 3) + ((quarter >> 1) << 2) + (l >> 2);
 		} else {
@@ -704,7 +709,9 @@ __global__ __launch_bounds__(MRT_DETECT_THREADS) void detect_grid_kernel(const v
 		// "coherent" was only the caller's word: if more than 1 in 8 neighbouring rays point
 		// somewhere else, the batch goes to the lane kernel (out[3] = 1) instead of packets
 		const unsigned long long n_wide = __hip_atomic_load(&scratch[1025], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-		out[3] = (n_wide * 8ull > (unsigned long long)m) ? 1u : 0u;
+		// ... and so does a small batch in which no row width was found: packets of 64 consecutive rays are no match for one lane
+		// per ray there (with a width, small batches go in pieces of 4 or 16 rays: api.hip quarter_small_grid)
+		out[3] = (n_wide * 8ull > (unsigned long long)m || (!ok && count < 32768ull)) ? 1u : 0u;
 		// the same four words to host-mapped memory: read by the host after it has waited for the stream
 		if (host_out) { host_out[0] = out[0]; host_out[1] = out[1]; host_out[2] = out[2]; host_out[3] = out[3]; }
 		scratch[1024] = 0ull; scratch[1025] = 0ull; // ticket / counter for the next launch (stream ordered)
@@ -828,8 +835,8 @@ hipError_t launch_trace(const TraceParams &p_in, bool any_hit, bool count, hipSt
 	if (p.tile_sched != nullptr && p.sched_hdr != nullptr && p.n_slots_max != 0u) threads = (uint64_t)p.n_slots_max * p.tile_unit * 64u; // (slots past sched_hdr[2] have nothing to do)
 	else if (p.lane_map == MAP_TILE8X8) {
 		const uint32_t th = 64u >> p.tile_w_log2;
-		threads = (uint64_t)p.tiles_x * ((p.rows + th - 1u) / th) * 64u * (p.quarter_all ? 4u : 1u);
-	} else threads = p.count * ((p.lane_map == MAP_AUTO && p.quarter_all) ? 4u : 1u); // (a width found on the device: whole tiles, count / 64 of them)
+		threads = (uint64_t)p.tiles_x * ((p.rows + th - 1u) / th) * 64u * (p.quarter_all == 2u ? 16u : (p.quarter_all ? 4u : 1u));
+	} else threads = p.count * ((p.lane_map == MAP_AUTO && p.quarter_all) ? (p.quarter_all == 2u ? 16u : 4u) : 1u); // (a width found on the device: whole tiles, count / 64 of them)
 	if (threads == 0) return hipSuccess;
 	const uint64_t blocks = (threads + MRT_WG - 1) / MRT_WG;
 	if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;

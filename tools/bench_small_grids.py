@@ -9,7 +9,7 @@ cfg = synth.CONFIGS[sys.argv[1] if len(sys.argv) > 1 else "C3"]
 scene = capi.Scene(synth.scene_vertices(cfg))
 c = capi.Context(0, kernel=int(sys.argv[2]) if len(sys.argv) > 2 else 5)
 scene.upload(c)
-for w, h in ((256, 256), (384, 384), (512, 512), (640, 360), (720, 405), (800, 450), (960, 540), (1024, 576)):
+for w, h in ((16, 12), (32, 32), (64, 64), (96, 96), (128, 128), (192, 192), (256, 256), (384, 384), (512, 512), (640, 360), (720, 405), (800, 450), (960, 540), (1024, 576)):
     cam = capi.camera_look(cfg["origin"], cfg["forward"], w, h, cfg["fov"])
     d_hits = c.device_alloc(w * h * 32)
     ts = []
