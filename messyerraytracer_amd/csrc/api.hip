@@ -648,7 +648,7 @@ void mrt_destroy(mrt_ctx *ctx)
 	release(ctx->idx_in); release(ctx->idx_out); release(ctx->sort_tmp); release(ctx->overflow);
 	if (ctx->sched.side) { (void)hipStreamSynchronize(ctx->sched.side); (void)hipStreamDestroy(ctx->sched.side); }
 	if (ctx->sched.traced) (void)hipEventDestroy(ctx->sched.traced);
-	for (int k = 0; k < 2; k++) { if (ctx->sched.ready[k]) (void)hipEventDestroy(ctx->sched.ready[k]); release(ctx->sched.cost[k]); release(ctx->sched.order[k]); }
+	for (int k = 0; k < 2; k++) { if (ctx->sched.ready[k]) (void)hipEventDestroy(ctx->sched.ready[k]); release(ctx->sched.cost[k]); release(ctx->sched.order[k]); release(ctx->sched.slots[k]); release(ctx->sched.hdr[k]); }
 	release(ctx->sched.cost_sorted); release(ctx->sched.iota); release(ctx->sched.tmp);
 	if (ctx->d_counters) (void)hipFree(ctx->d_counters);
 	if (ctx->build_arena.ptr) (void)hipFree(ctx->build_arena.ptr);
