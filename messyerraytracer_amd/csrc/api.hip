@@ -295,6 +295,8 @@ constexpr int kTuneFrames = 4; // frames per candidate of the grid kernel tuner 
 static bool schedule_applies(const mrt_ctx *ctx, const mrt::TraceParams &p);
 static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p);
 static int schedule_sort(mrt_ctx *ctx);
+static void tune_grid_kernel(mrt_ctx *ctx, mrt::TraceParams &p, int mode, uint32_t flags);
+static void tune_record(mrt_ctx *ctx);
 constexpr uint64_t kQuarterMinRays = 64, kQuarterMaxTiles = 3600, kSixteenthMaxTiles = 512; // small grids in quarter / sixteenth tiles: see quarter_small_grid()
 constexpr uint64_t kQuarterAllRays = 2048ull * 64ull; // up to here four quarters per tile still fit one round of waves: no schedule needed
 static void quarter_small_grid(const mrt_ctx *ctx, mrt::TraceParams &p);
@@ -410,6 +412,10 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 		p.quarter_all = 0u;
 		mrt::TraceParams g = p;
 		g.grid_w = ctx->h_auto[0]; g.rows = ctx->h_auto[1]; g.grid_h = g.rows; g.y0 = 0; g.tiles_x = ctx->h_auto[2];
+		// ... and so is the way it is cast: the grid tuner's candidates, as for a grid cast of that width (mrt_cast records the timing)
+		g.lane_map = mrt::MAP_TILE8X8;
+		tune_grid_kernel(ctx, g, mode, flags);
+		p.kernel = g.kernel; g.lane_map = p.lane_map;
 		if ((rc = schedule_grid(ctx, g))) return rc;
 		p.tile_sched = g.tile_sched; p.tile_cost = g.tile_cost; p.tile_unit = g.tile_unit; p.n_units = g.n_units; p.sched_hdr = g.sched_hdr; p.n_slots_max = g.n_slots_max;
 		scheduled = true;
@@ -1064,7 +1070,9 @@ int mrt_cast(mrt_ctx *ctx, const void *rays, void *hits, uint64_t count, uint32_
 		HIP_TRY(ctx, hipEventRecord(ctx->ev[5], ctx->stream));
 	}
 	HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-	return finish_timing(ctx, !(flags & MRT_FLAG_RAYS_ON_DEVICE), ctx->stats.last_kernel_launches >= 2, !hits_dev);
+	rc = finish_timing(ctx, !(flags & MRT_FLAG_RAYS_ON_DEVICE), ctx->stats.last_kernel_launches >= 2, !hits_dev);
+	if (rc == MRT_OK) tune_record(ctx);
+	return rc;
 }
 
 int mrt_submit(mrt_ctx *ctx, const void *rays, uint64_t count, uint32_t query_mask, int mode, uint32_t flags)

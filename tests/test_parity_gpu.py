@@ -311,6 +311,19 @@ def test_renderer_resolutions_on_the_c3_scene(built, wh):
         c.d2h(got, d_hits)
         parity.assert_exact(got, want, f"{w}x{h} frame {frame} ({c.last_kernel_variant()})")
     assert len(seen) == 2, seen       # both packet kernels were measured on this grid
+    if wh == (1920, 1080):
+        # the same rays read from memory, the width found on the device (the reference's cast_rays contract): from the second cast
+        # on the batch is scheduled, and tuned, by what the previous cast of as many rays found
+        d_rays = c.device_alloc(w * h * 32)
+        c.generate_grid(cam, w, h, 0, h, d_rays)
+        seen = set()
+        for frame in range(15):
+            c.cast(d_rays, d_hits, count=w * h, flags=capi.FLAG_COHERENT | capi.FLAG_RAYS_ON_DEVICE | capi.FLAG_HITS_ON_DEVICE)
+            seen.add(c.last_kernel_variant())
+            c.d2h(got, d_hits)
+            parity.assert_exact(got, want, f"{w}x{h} mrt_cast(COHERENT) frame {frame} ({c.last_kernel_variant()})")
+        assert len(seen) == 2, seen
+        c.device_free(d_rays)
     c.device_free(d_hits)
     c.close()
 
