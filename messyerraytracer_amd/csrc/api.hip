@@ -354,6 +354,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded (is_available() == false)");
 	if (mode != MRT_MODE_NEAREST && mode != MRT_MODE_ANY_HIT) return fail(ctx, MRT_ERR_INVALID, "bad mode");
 	if ((flags & MRT_FLAG_BOOL_OUT) && mode != MRT_MODE_ANY_HIT) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT needs any-hit mode");
+	ctx->tune.armed = false; // (the grid tuner times a cast only if THIS cast asks it to, and only mrt_cast / mrt_cast_grid record)
 	if ((flags & MRT_FLAG_BOOL_OUT) && (flags & MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT and TOKEN_OUT exclude each other");
 	const size_t rs = ray_stride(flags), hs = hit_stride(ctx, flags, mode);
 	int rc;
@@ -529,6 +530,7 @@ int cast_host_pipelined(mrt_ctx *ctx, const void *rays, void *hits, uint64_t cou
 		if (e != hipSuccess) break;
 		void *unused = nullptr;
 		rc = enqueue_cast(ctx, d_rays + off * rs, d_hits + off * hs, n, query_mask, mode, dev_flags, &unused);
+		ctx->tune.armed = false; // (chunks of a pipeline are not timed one by one)
 		if (rc) break;
 		if (ctx->stats.last_kernel_launches > launches) launches = ctx->stats.last_kernel_launches;
 		e = hipEventRecord(ctx->pipe_ev[2 * k + 1], ctx->stream);
@@ -1086,6 +1088,7 @@ int mrt_submit(mrt_ctx *ctx, const void *rays, uint64_t count, uint32_t query_ma
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	void *d_hits = nullptr;
 	int rc = enqueue_cast(ctx, rays, nullptr, count, query_mask, mode, flags, &d_hits);
+	ctx->tune.armed = false; // (collected later: no timing of this cast alone)
 	if (rc) return rc;
 	ctx->pending = true; ctx->pending_count = count; ctx->pending_flags = flags; ctx->pending_mode = mode;
 	ctx->pending_dev_hits = d_hits;
