@@ -45,6 +45,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     deps = srcs + [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
     if force or _stale(LIB, deps):
         extra = ["-DMRT_WITH_QUAD"] if os.environ.get("MRT_WITH_QUAD") == "1" else []
+        extra += os.environ.get("MRT_EXTRA_DEFINES", "").split()  # A/B builds of the tools (e.g. -DMRT_ASM_KPF=0)
         # one object per translation unit, compiled side by side (kernels.hip alone is over a minute), then one link
         os.makedirs(OBJ, exist_ok=True)
         objs = [os.path.join(OBJ, s.replace("/", "_") + ".o") for s in SOURCES]

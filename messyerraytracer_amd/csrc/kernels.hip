@@ -825,6 +825,7 @@ static void note_variant(const char *fmt, ...)
 #ifndef MRT_ROWS_WG_LARGE
 #define MRT_ROWS_WG_LARGE MRT_WG // threads per workgroup of the rows kernel on large scenes
 #endif
+constexpr uint32_t kPrefetchMaxWaves = 10240u; // 1.25 rounds of the device's 8 192 wave slots
 hipError_t launch_trace(const TraceParams &p_in, bool any_hit, bool count, hipStream_t stream)
 {
 	TraceParams p = p_in;
@@ -894,8 +895,17 @@ hipError_t launch_trace(const TraceParams &p_in, bool any_hit, bool count, hipSt
 		if (count) {
 			if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true, true>), grid, wg, p.extra_lds, stream, p);
 			else hipLaunchKernelGGL((trace_packet_asm_kernel<false, true>), grid, wg, p.extra_lds, stream, p);
-		} else if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true>), grid, wg, p.extra_lds, stream, p);
-		else hipLaunchKernelGGL((trace_packet_asm_kernel<false>), grid, wg, p.extra_lds, stream, p);
+		} else {
+			// the scalar-cache prefetch of both children: where the launch is about one round of waves (packet_asm_kernel.h)
+			// (a scheduled launch covers the slots the list MAY use: what counts is the units, or the one round the fill rule makes of fewer)
+			const uint64_t waves = p.tile_sched != nullptr && p.n_slots_max != 0u ? (p.n_units > 8192u ? p.n_units : (p.n_slots_max < 8192u ? p.n_slots_max : 8192u)) : threads / MRT_WAVE;
+			const bool kpf = waves <= kPrefetchMaxWaves;
+			if (kpf) { if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true, false, true>), grid, wg, p.extra_lds, stream, p);
+				else hipLaunchKernelGGL((trace_packet_asm_kernel<false, false, true>), grid, wg, p.extra_lds, stream, p); }
+			else if (any_hit) hipLaunchKernelGGL((trace_packet_asm_kernel<true>), grid, wg, p.extra_lds, stream, p);
+			else hipLaunchKernelGGL((trace_packet_asm_kernel<false>), grid, wg, p.extra_lds, stream, p);
+			if (kpf) { note_variant("trace_packet_asm_kernel<%s, false, true>", MRT_B(any_hit)); return hipGetLastError(); }
+		}
 		note_variant("trace_packet_asm_kernel<%s, %s>", MRT_B(any_hit), MRT_B(count));
 		return hipGetLastError();
 	}

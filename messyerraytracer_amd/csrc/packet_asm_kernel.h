@@ -39,7 +39,25 @@
 // the leaf's mask at LDS [sp + 8]: left there by the pop, or written on the way out when the leaf was
 // entered straight from its parent.  Inner steps pay nothing for this; a push pays one s_cselect_b64, two
 // v_mov and a ds_write_b64.
-#define MRT_ASM_NODE_LOOP(CNT, LNX, LFX, LNY, LFY, LNZ, LFZ, RNX, RFX, RNY, RFY, RNZ, RFZ)                      \
+// The rows of both children towards the scalar cache while the 22 vector instructions of the two slab tests run: the fetch of
+// whichever is entered next then waits less (a leaf child's ref indexes triangles, not node rows: skipped).  Nothing waits for the
+// two dwords; s62 / s63 are never read.
+// It pays where a launch is about one round of waves and a walk's time is its chain of fetches (small grids, grids cast in
+// pieces: C3 scene 16x12 0.149 -> 0.138 ms, 128^2 0.183 -> 0.164, 384^2 0.246 -> 0.231, 640x360 0.232 -> 0.221, 1024x576 0.275 ->
+// 0.258) and costs where the chip is full and the scalar unit is what walks share (1280x720 0.274 -> 0.282, 1920x1080 0.447 ->
+// 0.469, 4096^2 2.16 -> 2.29): a template parameter of the kernel, chosen by the launch (launch_trace).
+#define MRT_ASM_KPREFETCH_ON                                                                                    \
+		"s_bitcmp1_b32 s39, 31\n"                                                                           \
+		"s_cbranch_scc1 L_kl_%=\n"                                                                          \
+		"s_lshl_b32 s62, s39, 6\n"                                                                          \
+		"s_load_dword s62, %[base], s62\n"                                                                  \
+		"L_kl_%=:\n"                                                                                        \
+		"s_bitcmp1_b32 s43, 31\n"                                                                           \
+		"s_cbranch_scc1 L_kr_%=\n"                                                                          \
+		"s_lshl_b32 s63, s43, 6\n"                                                                          \
+		"s_load_dword s63, %[base], s63\n"                                                                  \
+		"L_kr_%=:\n"
+#define MRT_ASM_NODE_LOOP(CNT, KPF, LNX, LFX, LNY, LFY, LNZ, LFZ, RNX, RFX, RNY, RFY, RNZ, RFZ)                      \
 	asm volatile(                                                                                           \
 		"s_cmp_eq_u32 %[dopop], 1\n"                                                                        \
 		"s_cbranch_scc1 L_pop_%=\n"                                                                         \
@@ -49,6 +67,7 @@
 		"s_lshl_b32 s52, %[node], 6\n"                                                                      \
 		"s_load_dwordx16 s[36:51], %[base], s52\n"                                                          \
 		"s_waitcnt lgkmcnt(0)\n"                                                                            \
+		KPF                                                                                                 \
 		"v_fma_f32 v50, " LNX ", %[ix], %[nrx]\n"                                                           \
 		"v_fma_f32 v51, " LNY ", %[iy], %[nry]\n"                                                           \
 		"v_fma_f32 v52, " LNZ ", %[iz], %[nrz]\n"                                                           \
@@ -116,24 +135,24 @@
 		"s_cmp_lt_u32 %[node], 0x7fffffff\n"                                                                \
 		"s_cbranch_scc1 L_node_%=\n"                                                                        \
 		"L_exit_%=:\n"                                                                                      \
-		"s_waitcnt vmcnt(0)\n"              /* no prefetch may land in v58 once the compiler owns it again */ \
+		"s_waitcnt vmcnt(0) lgkmcnt(0)\n"   /* no prefetch may land in v58 / s62 / s63 once the compiler owns them again */ \
 		: [node] "+s"(node), [sp] "+v"(sp), [cnt] "+s"(cnt)                                                 \
 		: [base] "s"(base), [dopop] "s"(dopop), [ix] "v"(ix), [iy] "v"(iy), [iz] "v"(iz), [nrx] "v"(nrx),   \
 		  [nry] "v"(nry), [nrz] "v"(nrz), [tmin] "v"(tmin), [lim] "v"(lim)                                  \
 		: "vcc", "scc", "s36", "s37", "s38", "s39", "s40", "s41", "s42", "s43", "s44", "s45",      \
-		  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", \
+		  "s46", "s47", "s48", "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63", \
 		  "v50", "v51", "v52", "v53", "v54", "v55", "v58")
 
 // Walks inner nodes until `node` is a leaf reference (>= 0x80000000) or the sentinel
 // (0x7FFFFFFF = the stack ran empty).  dopop = 1: start by popping (after a leaf).
 #define MRT_ASM_COUNT_STEP "s_add_u32 %[cnt], %[cnt], 1\n"
-template <int OCT, bool COUNT>
+template <int OCT, bool COUNT, bool KPF = false>
 __device__ __forceinline__ void packet_node_loop_asm(const DevNode *base, uint32_t &node, uint32_t &sp, uint32_t dopop, uint32_t &cnt,
 		float ix, float iy, float iz, float nrx, float nry, float nrz, float tmin, float lim)
 {
 	// per axis: inv >= 0 -> near plane = min, far plane = max; inv < 0 -> swapped
 #define MRT_ASM_OCT(O, ...) \
-	if (OCT == O) { if (COUNT) MRT_ASM_NODE_LOOP(MRT_ASM_COUNT_STEP, __VA_ARGS__); else MRT_ASM_NODE_LOOP("", __VA_ARGS__); }
+	if (OCT == O) { if (COUNT) MRT_ASM_NODE_LOOP(MRT_ASM_COUNT_STEP, "", __VA_ARGS__); else if (KPF) MRT_ASM_NODE_LOOP("", MRT_ASM_KPREFETCH_ON, __VA_ARGS__); else MRT_ASM_NODE_LOOP("", "", __VA_ARGS__); }
 	MRT_ASM_OCT(0, "s36", "s40", "s37", "s41", "s38", "s42", "s44", "s48", "s45", "s49", "s46", "s50")
 	MRT_ASM_OCT(1, "s40", "s36", "s37", "s41", "s38", "s42", "s48", "s44", "s45", "s49", "s46", "s50")
 	MRT_ASM_OCT(2, "s36", "s40", "s41", "s37", "s38", "s42", "s44", "s48", "s49", "s45", "s46", "s50")
@@ -190,7 +209,7 @@ __device__ __forceinline__ void packet_leaf(const TraceParams &p, const float4 *
 	} while (!last);
 }
 
-template <int OCT, bool ANY_HIT, bool COUNT = false>
+template <int OCT, bool ANY_HIT, bool COUNT = false, bool KPF = false>
 __device__ __forceinline__ void packet_traverse_asm(const TraceParams &p, const RayRegs &r, uint32_t sp,
 		float &best_t, float &best_u, float &best_v, uint32_t &best_slot,
 		uint32_t &n_nodes, uint32_t &n_tris, // COUNT: wave-uniform numbers of node steps and triangle rows fetched
@@ -208,7 +227,7 @@ __device__ __forceinline__ void packet_traverse_asm(const TraceParams &p, const 
 	uint32_t dopop = 0;
 	uint32_t steps = 0;  // COUNT: node steps of this walk (an SGPR inside the asm block)
 	for (;;) {
-		packet_node_loop_asm<OCT, COUNT>(p.nodes, cur, sp, dopop, steps, ix, iy, iz, nrx, nry, nrz, r.t_min, lim_t);
+		packet_node_loop_asm<OCT, COUNT, KPF>(p.nodes, cur, sp, dopop, steps, ix, iy, iz, nrx, nry, nrz, r.t_min, lim_t);
 		cur = __builtin_amdgcn_readfirstlane(cur);
 		steps = __builtin_amdgcn_readfirstlane(steps); // (tells the compiler the asm operand stays wave-uniform)
 		if (cur == kSentinel) break;
@@ -225,7 +244,7 @@ __device__ __forceinline__ void packet_traverse_asm(const TraceParams &p, const 
 	if (best_id_io) *best_id_io = best_id;
 }
 
-template <bool ANY_HIT, bool COUNT = false>
+template <bool ANY_HIT, bool COUNT = false, bool KPF = false>
 __global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_num_sgpr(80))) void trace_packet_asm_kernel(const TraceParams p) // (80 scalar registers: 8 waves per SIMD; 81-96 would be 7)
 {
 	// 16-byte stack entries {ref, -, lane mask}; entry 0 holds the sentinel
@@ -262,7 +281,7 @@ __global__ __launch_bounds__(MRT_WG) __attribute__((amdgpu_num_sgpr(80))) void t
 		// private stack — so that the compiler keeps the triangle fetches of the leaf code scalar)
 		*(volatile uint32_t *)&stack[0] = kSentinel;
 		const uint32_t sp = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)(stack + 4);
-#define MRT_PKTA(O) case O: packet_traverse_asm<O, ANY_HIT, COUNT>(p, r, sp, best_t, best_u, best_v, best_slot, n_nodes, n_tris); break;
+#define MRT_PKTA(O) case O: packet_traverse_asm<O, ANY_HIT, COUNT, KPF>(p, r, sp, best_t, best_u, best_v, best_slot, n_nodes, n_tris); break;
 		switch (oct) { MRT_PKTA(0) MRT_PKTA(1) MRT_PKTA(2) MRT_PKTA(3) MRT_PKTA(4) MRT_PKTA(5) MRT_PKTA(6) MRT_PKTA(7) }
 #undef MRT_PKTA
 	}
