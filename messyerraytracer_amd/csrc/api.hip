@@ -93,13 +93,22 @@ struct mrt_ctx {
 		hipStream_t side = nullptr;
 		hipEvent_t traced = nullptr, ready[2] = {nullptr, nullptr};
 		void forget() { have_order[0] = have_order[1] = false; }
-	} sched;
+	};
 	// How a mid-size grid is cast is MEASURED per grid (tune_grid_kernel): four frames with the 64-ray kernel, four with the 128-ray
 	// walk and its most expensive units launched in pieces, four with the 128-ray walk and every unit whole; from frame 12 on the
 	// fastest of the three, each judged by the faster of its last two frames.  What wins flips with the number of rounds a grid
 	// makes on the chip (C3 scene: 1280x720 the 64-ray kernel, 1280x960 the 128-ray walk whole, 1920x1080 the 128-ray walk in pieces).
 	uint64_t last_detect_count = 0;   // rays of the last cast whose row width was looked for on the device (h_auto holds what it found)
-	struct GridTune { uint32_t grid_w = 0, grid_h = 0, y0 = 0, rows = 0; int mode = -1; int phase = 0; float t_asm = 0.0f, t_dual = 0.0f, t_whole = 0.0f; bool armed = false, no_pieces = false; } tune;
+	struct GridTune { uint32_t grid_w = 0, grid_h = 0, y0 = 0, rows = 0; int mode = -1; int phase = 0; float t_asm = 0.0f, t_dual = 0.0f, t_whole = 0.0f; bool armed = false, no_pieces = false; };
+	// What has been learnt about a grid (its tile schedule, how it is cast fastest) is kept per grid AND cast mode, for the last few
+	// of them: a renderer that casts two views, or closest-hit and any-hit rays of one view, or the row-block chunks of a sharded
+	// frame, in turn, keeps every one's state (with one state each change of grid threw the other's away, and cost a stream
+	// synchronisation and an upload to start over).  select_grid_state() picks the entry of a cast; the least recently used one goes.
+	struct GridState { TileSchedule sched; GridTune tune; uint32_t k_w = 0, k_h = 0, k_y0 = 0, k_rows = 0; int k_mode = -1; uint64_t stamp = 0; };
+	static constexpr int kGridStates = 8;
+	GridState grid_states[kGridStates];
+	GridState *gs = &grid_states[0];
+	uint64_t gs_clock = 0;
 	char queued_variant[96] = "", queued_alt_variant[96] = "", last_variant[96] = ""; // instantiation names (mrt_last_kernel_variant)
 	uint32_t queued_kernel = 0, queued_alt_kernel = 0; bool queued_detect = false; // what the last enqueue_cast put on the stream
 	// host-array pipeline (cast_host_pipelined): copy streams and per-chunk events, created on first use
@@ -163,7 +172,7 @@ void free_scene(mrt_ctx *ctx)
 	ctx->d_nodes = nullptr; ctx->d_hot = nullptr; ctx->d_cold = nullptr; ctx->d_nodes4 = nullptr; ctx->d_nodes8 = nullptr;
 	ctx->n_nodes8 = ctx->stack8 = 0;
 	ctx->scene = false; ctx->n_nodes = ctx->n_tris = 0;
-	ctx->sched.forget(); ctx->tune.phase = 0; ctx->tune.mode = -1; // what was learnt about the old scene's grids
+	for (auto &g : ctx->grid_states) { g.sched.forget(); g.tune.phase = 0; g.tune.mode = -1; } // what was learnt about the old scene's grids
 }
 
 size_t ray_stride(uint32_t flags) { return (flags & MRT_FLAG_HOST_LAYOUT) ? sizeof(mrt_host_ray60) : sizeof(mrt_ray32); }
@@ -295,6 +304,18 @@ constexpr int kTuneFrames = 4; // frames per candidate of the grid kernel tuner 
 static bool schedule_applies(const mrt_ctx *ctx, const mrt::TraceParams &p);
 static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p);
 static int schedule_sort(mrt_ctx *ctx);
+// the state of this grid and cast mode (mrt_ctx::GridState): the entry that holds it, else the least recently used one
+static void select_grid_state(mrt_ctx *ctx, uint32_t w, uint32_t h, uint32_t y0, uint32_t rows, int mode)
+{
+	mrt_ctx::GridState *pick = nullptr, *oldest = &ctx->grid_states[0];
+	for (auto &g : ctx->grid_states) {
+		if (g.k_mode == mode && g.k_w == w && g.k_h == h && g.k_y0 == y0 && g.k_rows == rows) { pick = &g; break; }
+		if (g.stamp < oldest->stamp) oldest = &g;
+	}
+	if (!pick) { pick = oldest; pick->k_w = w; pick->k_h = h; pick->k_y0 = y0; pick->k_rows = rows; pick->k_mode = mode; }
+	pick->stamp = ++ctx->gs_clock;
+	ctx->gs = pick;
+}
 static void tune_grid_kernel(mrt_ctx *ctx, mrt::TraceParams &p, int mode, uint32_t flags);
 static void tune_record(mrt_ctx *ctx);
 constexpr uint64_t kQuarterMinRays = 64, kQuarterMaxTiles = 3600, kSixteenthMaxTiles = 512; // small grids in quarter / sixteenth tiles: see quarter_small_grid()
@@ -354,7 +375,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	if (!ctx->scene) return fail(ctx, MRT_ERR_NO_SCENE, "no scene uploaded (is_available() == false)");
 	if (mode != MRT_MODE_NEAREST && mode != MRT_MODE_ANY_HIT) return fail(ctx, MRT_ERR_INVALID, "bad mode");
 	if ((flags & MRT_FLAG_BOOL_OUT) && mode != MRT_MODE_ANY_HIT) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT needs any-hit mode");
-	ctx->tune.armed = false; // (the grid tuner times a cast only if THIS cast asks it to, and only mrt_cast / mrt_cast_grid record)
+	ctx->gs->tune.armed = false; // (the grid tuner times a cast only if THIS cast asks it to, and only mrt_cast / mrt_cast_grid record)
 	if ((flags & MRT_FLAG_BOOL_OUT) && (flags & MRT_FLAG_TOKEN_OUT)) return fail(ctx, MRT_ERR_INVALID, "BOOL_OUT and TOKEN_OUT exclude each other");
 	const size_t rs = ray_stride(flags), hs = hit_stride(ctx, flags, mode);
 	int rc;
@@ -414,6 +435,7 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 		mrt::TraceParams g = p;
 		g.grid_w = ctx->h_auto[0]; g.rows = ctx->h_auto[1]; g.grid_h = g.rows; g.y0 = 0; g.tiles_x = ctx->h_auto[2];
 		// ... and so is the way it is cast: the grid tuner's candidates, as for a grid cast of that width (mrt_cast records the timing)
+		select_grid_state(ctx, g.grid_w, g.grid_h, 0u, g.rows, mode);
 		g.lane_map = mrt::MAP_TILE8X8;
 		tune_grid_kernel(ctx, g, mode, flags);
 		p.kernel = g.kernel; g.lane_map = p.lane_map;
@@ -530,7 +552,7 @@ int cast_host_pipelined(mrt_ctx *ctx, const void *rays, void *hits, uint64_t cou
 		if (e != hipSuccess) break;
 		void *unused = nullptr;
 		rc = enqueue_cast(ctx, d_rays + off * rs, d_hits + off * hs, n, query_mask, mode, dev_flags, &unused);
-		ctx->tune.armed = false; // (chunks of a pipeline are not timed one by one)
+		ctx->gs->tune.armed = false; // (chunks of a pipeline are not timed one by one)
 		if (rc) break;
 		if (ctx->stats.last_kernel_launches > launches) launches = ctx->stats.last_kernel_launches;
 		e = hipEventRecord(ctx->pipe_ev[2 * k + 1], ctx->stream);
@@ -654,10 +676,13 @@ void mrt_destroy(mrt_ctx *ctx)
 	free_scene(ctx);
 	release(ctx->rays); release(ctx->hits); release(ctx->keys_in); release(ctx->keys_out);
 	release(ctx->idx_in); release(ctx->idx_out); release(ctx->sort_tmp); release(ctx->overflow);
-	if (ctx->sched.side) { (void)hipStreamSynchronize(ctx->sched.side); (void)hipStreamDestroy(ctx->sched.side); }
-	if (ctx->sched.traced) (void)hipEventDestroy(ctx->sched.traced);
-	for (int k = 0; k < 2; k++) { if (ctx->sched.ready[k]) (void)hipEventDestroy(ctx->sched.ready[k]); release(ctx->sched.cost[k]); release(ctx->sched.order[k]); release(ctx->sched.slots[k]); release(ctx->sched.hdr[k]); }
-	release(ctx->sched.cost_sorted); release(ctx->sched.iota); release(ctx->sched.tmp);
+	for (auto &g : ctx->grid_states) {
+		auto &sc = g.sched;
+		if (sc.side) { (void)hipStreamSynchronize(sc.side); (void)hipStreamDestroy(sc.side); }
+		if (sc.traced) (void)hipEventDestroy(sc.traced);
+		for (int k = 0; k < 2; k++) { if (sc.ready[k]) (void)hipEventDestroy(sc.ready[k]); release(sc.cost[k]); release(sc.order[k]); release(sc.slots[k]); release(sc.hdr[k]); }
+		release(sc.cost_sorted); release(sc.iota); release(sc.tmp);
+	}
 	if (ctx->d_counters) (void)hipFree(ctx->d_counters);
 	if (ctx->build_arena.ptr) (void)hipFree(ctx->build_arena.ptr);
 	if (ctx->build_arena.pinned) (void)hipHostFree(ctx->build_arena.pinned);
@@ -1088,7 +1113,7 @@ int mrt_submit(mrt_ctx *ctx, const void *rays, uint64_t count, uint32_t query_ma
 	HIP_TRY(ctx, hipSetDevice(ctx->device));
 	void *d_hits = nullptr;
 	int rc = enqueue_cast(ctx, rays, nullptr, count, query_mask, mode, flags, &d_hits);
-	ctx->tune.armed = false; // (collected later: no timing of this cast alone)
+	ctx->gs->tune.armed = false; // (collected later: no timing of this cast alone)
 	if (rc) return rc;
 	ctx->pending = true; ctx->pending_count = count; ctx->pending_flags = flags; ctx->pending_mode = mode;
 	ctx->pending_dev_hits = d_hits;
@@ -1209,14 +1234,14 @@ static bool schedule_applies(const mrt_ctx *ctx, const mrt::TraceParams &p)
 constexpr uint32_t kScheduleRenew = 8;
 static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p)
 {
-	auto &s = ctx->sched;
+	auto &s = ctx->gs->sched;
 	const uint32_t th = 64u >> p.tile_w_log2;
 	const uint32_t tiles_y = (p.rows + th - 1u) / th;
 	const uint32_t unit = p.kernel == MRT_KERNEL_PACKET_DUAL ? 2u : 1u;
 	const uint64_t tiles = (uint64_t)p.tiles_x * tiles_y;
 	const uint32_t n_units = (uint32_t)((tiles + unit - 1u) / unit);
 	// pieces: 8x8 tiles only, ids within the entry's 28 bits, not while the kernel tuner tries (or has chosen) the frames without
-	const bool pieces = p.tile_w_log2 == 3u && ctx->opts.tile_schedule != 2u && tiles < (1ull << 28) && !ctx->tune.no_pieces;
+	const bool pieces = p.tile_w_log2 == 3u && ctx->opts.tile_schedule != 2u && tiles < (1ull << 28) && !ctx->gs->tune.no_pieces;
 	const bool same = s.grid_w == p.grid_w && s.grid_h == p.grid_h && s.y0 == p.y0 && s.rows == p.rows && s.unit == unit &&
 			s.n_units == n_units && s.tile_w_log2 == p.tile_w_log2 && s.pieces == pieces;
 	int rc;
@@ -1245,7 +1270,7 @@ static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p)
 	// the order to launch in: the last generation's if its sort is done, else the one before (still intact in slot `cur`:
 	// that slot's ORDER array is rewritten only by the next sort, which runs after this frame's trace)
 	// the frame the kernel tuner times (the third of a kernel) waits for the sorts behind it: it is launched the way later frames will be
-	if (ctx->tune.armed && ctx->tune.phase % kTuneFrames >= kTuneFrames - 2) HIP_TRY(ctx, hipStreamSynchronize(s.side));
+	if (ctx->gs->tune.armed && ctx->gs->tune.phase % kTuneFrames >= kTuneFrames - 2) HIP_TRY(ctx, hipStreamSynchronize(s.side));
 	const uint32_t *order = nullptr, *hdr = nullptr;
 	if (s.have_order[newest] && hipEventQuery(s.ready[newest]) == hipSuccess) { order = (const uint32_t *)s.slots[newest].ptr; hdr = (const uint32_t *)s.hdr[newest].ptr; }
 	(void)hipGetLastError(); // (hipErrorNotReady is not an error)
@@ -1265,7 +1290,7 @@ static int schedule_grid(mrt_ctx *ctx, mrt::TraceParams &p)
 // side stream.
 static int schedule_sort(mrt_ctx *ctx)
 {
-	auto &s = ctx->sched;
+	auto &s = ctx->gs->sched;
 	s.frame++;
 	if (!s.measuring) return MRT_OK;
 	const uint32_t cur = s.gen & 1u;
@@ -1322,7 +1347,7 @@ static void quarter_small_grid(const mrt_ctx *ctx, mrt::TraceParams &p)
 // casts (a timing is needed), grids the schedule applies to.
 static void tune_grid_kernel(mrt_ctx *ctx, mrt::TraceParams &p, int mode, uint32_t flags)
 {
-	auto &t = ctx->tune;
+	auto &t = ctx->gs->tune;
 	t.armed = false; t.no_pieces = false;
 	if (ctx->opts.kernel != MRT_KERNEL_AUTO || ctx->two_level || !ctx->d_rows || ctx->opts.count_visits || ctx->opts.tile_schedule == 1u) return;
 	// (from 2^22 rays on the 128-ray walk won every measurement -- 2560x1440 .. 7680x4320, C5's row blocks --: no frames are spent on the other one)
@@ -1345,7 +1370,7 @@ static void tune_grid_kernel(mrt_ctx *ctx, mrt::TraceParams &p, int mode, uint32
 }
 static void tune_record(mrt_ctx *ctx)
 {
-	auto &t = ctx->tune;
+	auto &t = ctx->gs->tune;
 	if (!t.armed) return;
 	// the faster of a candidate's last two frames (both launched in a measured order: schedule_grid waits for the sorts behind them)
 	const int cand = t.phase / kTuneFrames, at = t.phase % kTuneFrames;
@@ -1407,6 +1432,7 @@ int mrt_cast_grid(mrt_ctx *ctx, const mrt_camera *cam, uint32_t grid_w, uint32_t
 	p.lane_map = ctx->opts.grid_tile == 1 ? mrt::MAP_LINEAR : mrt::MAP_TILE8X8;
 	p.kernel = pick_kernel(ctx, true, p.count);
 	quarter_small_grid(ctx, p);
+	if (p.count >= kScheduleMinRays) select_grid_state(ctx, p.grid_w, p.grid_h, p.y0, p.rows, mode);
 	tune_grid_kernel(ctx, p, mode, flags);
 	const bool scheduled = schedule_applies(ctx, p) && !(p.quarter_all && p.count <= kQuarterAllRays);
 	if (scheduled) p.quarter_all = 0u; // (from 2 048 tiles on the cost history says WHICH tiles go in quarters)

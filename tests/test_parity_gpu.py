@@ -250,6 +250,28 @@ def test_frame_coherent_tile_schedule_changes_no_record(built, kernel, monkeypat
         c.close()
 
 
+def test_interleaved_views_keep_their_schedules(built, monkeypatch):
+    """What is learnt about a grid (tile schedule, pieces, how it is cast fastest) is kept per grid and cast mode for the last
+    eight of them (api.hip select_grid_state): three views and two modes cast in turn, fourteen rounds -- every record of every
+    cast against the oracle, whatever state each cast found."""
+    monkeypatch.setenv("MRT_SCHEDULE_MIN_LOG2", "15")
+    monkeypatch.setenv("MRT_SCHED_SPLIT_PCT", "5")
+    v = synth.soup(20000, 0.25, 37)
+    scene, osc = capi.Scene(v), po.OracleScene(v)
+    views = []
+    for (w, h, origin, fwd) in ((640, 384, (0, 0, -12), (0, 0, 1)), (512, 256, (2, 1, -11), (-0.1, 0, 1)), (400, 300, (0, 0, -12), (0, 0.05, 1))):
+        views.append((w, h, capi.camera_look(origin, fwd, w, h, 50.0), osc.trace(po.grid_rays(origin, fwd, w, h, 50.0))))
+    for kernel in (capi.KERNEL_PACKET_ASM, capi.KERNEL_PACKET_DUAL):
+        c = capi.Context(0, kernel=kernel)
+        scene.upload(c)
+        for rnd in range(14):
+            for (w, h, cam, want) in views:
+                parity.assert_exact(c.cast_grid(cam, w, h), want, f"kernel {kernel} round {rnd} {w}x{h}")
+                b = c.cast_grid(cam, w, h, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT)
+                assert np.array_equal(b.astype(bool), want["prim_id"] >= 0), (kernel, rnd, w, h)
+        c.close()
+
+
 def test_small_grids_in_quarter_tiles(built):
     """Grids of 64 rays up to 3 600 tiles are cast by the packet kernel with every tile launched in pieces -- up to 512 tiles as
     sixteen 2x2-pixel sixteenths (4 rays in lanes 0..3 of a wave), above as four 4x4-pixel quarters (16 rays; api.hip
