@@ -340,6 +340,16 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 	if ((wide4 || wide8) && can_count) persistent = true;
 	if (!persistent || !can_count) {
 		p.kernel = ctx->two_level ? mrt::MRT_KERNEL_TWO_LEVEL : MRT_KERNEL_LANE;
+		// A small batch on more, emptier waves: with fewer rays than the device has wave slots (8 192) every ray gets a wave of its
+		// own, up to 2^15 rays two or four share one.  A wave's walk is as long as its longest ray's and every step costs as many
+		// memory requests as it has rays; a batch this small ends with its longest wave (blocking mrt_cast of incoherent rays in
+		// host arrays: 256 rays 190 -> 97 us, 1 024 rays 247 -> 125, 4 096 rays 317 -> 210; 2^14 device-resident rays 503 -> 338;
+		// profiles/r03_latency.txt)
+		if (p.lane_map == mrt::MAP_LINEAR && !ctx->two_level && count <= (8192u << 2)) {
+			uint32_t lanes = 1u;
+			while ((count + lanes - 1u) / lanes > 8192u) lanes <<= 1;
+			p.sparse_lanes = lanes;
+		}
 		HIP_TRY(ctx, mrt::launch_trace(p, any_hit, ctx->opts.count_visits != 0, ctx->stream));
 		ctx->queued_kernel = p.kernel; std::snprintf(ctx->queued_variant, sizeof(ctx->queued_variant), "%s", mrt::last_trace_variant());
 		return MRT_OK;

@@ -145,6 +145,7 @@ __device__ __forceinline__ bool lane_ray_index_g(const TraceParams &p, uint64_t 
 		ray_idx = (uint64_t)py * grid_w + px;
 		return true;
 	}
+	if (p.sparse_lanes) { const uint32_t l = (uint32_t)g & 63u; if (l >= p.sparse_lanes) return false; g = (g >> 6) * p.sparse_lanes + l; }
 	if (g >= p.count) return false;
 	ray_idx = p.perm ? (uint64_t)p.perm[g] : g;
 	if (p.in_fmt == IN_GRID) { px = (uint32_t)(ray_idx % p.grid_w); py = (uint32_t)(ray_idx / p.grid_w); }
@@ -837,7 +838,8 @@ hipError_t launch_trace(const TraceParams &p_in, bool any_hit, bool count, hipSt
 	else if (p.lane_map == MAP_TILE8X8) {
 		const uint32_t th = 64u >> p.tile_w_log2;
 		threads = (uint64_t)p.tiles_x * ((p.rows + th - 1u) / th) * 64u * (p.quarter_all == 2u ? 16u : (p.quarter_all ? 4u : 1u));
-	} else threads = p.count * ((p.lane_map == MAP_AUTO && p.quarter_all) ? (p.quarter_all == 2u ? 16u : 4u) : 1u); // (a width found on the device: whole tiles, count / 64 of them)
+	} else if (p.lane_map == MAP_LINEAR && p.sparse_lanes) threads = (p.count + p.sparse_lanes - 1u) / p.sparse_lanes * 64u;
+	else threads = p.count * ((p.lane_map == MAP_AUTO && p.quarter_all) ? (p.quarter_all == 2u ? 16u : 4u) : 1u); // (a width found on the device: whole tiles, count / 64 of them)
 	if (threads == 0) return hipSuccess;
 	const uint64_t blocks = (threads + MRT_WG - 1) / MRT_WG;
 	if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;

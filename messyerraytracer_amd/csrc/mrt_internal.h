@@ -148,6 +148,7 @@ struct TraceParams {
 	// tile s >> 2, 16 rays in lanes 0..15) -- a grid of fewer tiles than the device has wave slots lasts as long as its longest
 	// walk, and a quarter tile's walk is about half as long as its tile's.
 	uint32_t quarter_all;
+	uint32_t sparse_lanes;     // linear lane map of the lane kernel: rays per wave, in lanes 0 .. sparse_lanes - 1 (0 = 64): a small batch on more, emptier waves (api.hip launch_lane)
 	uint32_t kernel;           // MRT_KERNEL_LANE / MRT_KERNEL_PACKET
 	uint32_t stack_depth;      // LDS stack entries per lane
 	uint32_t xcd_swizzle;      // 1: remap blockIdx so each XCD owns a contiguous band
