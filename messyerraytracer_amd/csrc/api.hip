@@ -344,8 +344,8 @@ int launch_lane(mrt_ctx *ctx, mrt::TraceParams &p, uint64_t count, bool any_hit,
 		// own, up to 2^15 rays two or four share one.  A wave's walk is as long as its longest ray's and every step costs as many
 		// memory requests as it has rays; a batch this small ends with its longest wave (blocking mrt_cast of incoherent rays in
 		// host arrays: 256 rays 190 -> 97 us, 1 024 rays 247 -> 125, 4 096 rays 317 -> 210; 2^14 device-resident rays 503 -> 338;
-		// profiles/r03_latency.txt)
-		if (p.lane_map == mrt::MAP_LINEAR && !ctx->two_level && count <= (8192u << 2)) {
+		// on the C5 two-level scene 256 rays 1 649 -> 319 us, 4 096 rays 2 272 -> 646; profiles/r03_latency.txt)
+		if (p.lane_map == mrt::MAP_LINEAR && count <= (8192u << 2)) {
 			uint32_t lanes = 1u;
 			while ((count + lanes - 1u) / lanes > 8192u) lanes <<= 1;
 			p.sparse_lanes = lanes;
@@ -431,9 +431,10 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	}
 	// a small batch whose width the device finds: sixteenth or quarter tiles (quarter_small_grid; if no width is found the lanes stay
 	// linear and the waves past the batch have nothing to do)
-	if (detect && ctx->opts.kernel == MRT_KERNEL_AUTO && !ctx->two_level && !ctx->opts.count_visits && p.tile_w_log2 == 3u && p.n_nodes < mrt::kAsmNodeLimit &&
-			count >= kQuarterMinRays && count <= kQuarterMaxTiles * 64u && (p.kernel == MRT_KERNEL_PACKET_ASM || p.kernel == MRT_KERNEL_LANE)) {
-		p.kernel = MRT_KERNEL_PACKET_ASM; p.quarter_all = count <= kSixteenthMaxTiles * 64u ? 2u : 1u;
+	if (detect && ctx->opts.kernel == MRT_KERNEL_AUTO && !ctx->opts.count_visits && p.tile_w_log2 == 3u && p.n_nodes < mrt::kAsmNodeLimit &&
+			count >= kQuarterMinRays && count <= kQuarterMaxTiles * 64u && (p.kernel == MRT_KERNEL_PACKET_ASM || p.kernel == MRT_KERNEL_LANE ||
+				p.kernel == mrt::MRT_KERNEL_TWO_LEVEL_PACKET || p.kernel == mrt::MRT_KERNEL_TWO_LEVEL)) {
+		p.kernel = ctx->two_level ? mrt::MRT_KERNEL_TWO_LEVEL_PACKET : MRT_KERNEL_PACKET_ASM; p.quarter_all = count <= kSixteenthMaxTiles * 64u ? 2u : 1u;
 	}
 	if (ctx->opts.count_visits) HIP_TRY(ctx, hipMemsetAsync(ctx->d_counters, 0, mrt::kNumCounters * sizeof(unsigned long long), ctx->stream));
 	const bool any = mode == MRT_MODE_ANY_HIT;
@@ -1344,12 +1345,14 @@ static int schedule_sort(mrt_ctx *ctx)
 // 0.25, 640x360 0.38 / 0.55 / 0.29; sixteen times as many waves are two rounds of them from 1 024 tiles on, four times as many from
 // 4 096 (512^2: 0.32 / 0.55 / 0.32), and nothing is gained.  The C2 scene draws the same lines (64^2 0.38 / 0.27 / 0.18 / 0.09;
 // 192^2 - / - / 0.10 / 0.10; 256^2 - / - / 0.09 / 0.15).  Between 2 048 and 8 192 tiles the cost history picks the tiles (schedule_plan_kernel).
+// Two-level scenes go the same way with their own packet kernel (whose walks are longer still: a ray crosses several instances):
+// C5 as a two-level scene, 64^2 2.56 -> 0.95 ms, 128^2 2.78 -> 0.83, 256^2 4.14 -> 1.73, 640x360 2.10 -> 1.79.
 static void quarter_small_grid(const mrt_ctx *ctx, mrt::TraceParams &p)
 {
-	if (ctx->opts.kernel != MRT_KERNEL_AUTO || ctx->two_level || ctx->opts.count_visits || p.lane_map != mrt::MAP_TILE8X8 || p.tile_w_log2 != 3u) return;
+	if (ctx->opts.kernel != MRT_KERNEL_AUTO || ctx->opts.count_visits || p.lane_map != mrt::MAP_TILE8X8 || p.tile_w_log2 != 3u) return;
 	if (p.n_nodes >= mrt::kAsmNodeLimit || p.count < kQuarterMinRays) return;
 	if ((uint64_t)p.tiles_x * ((p.rows + 7u) / 8u) > kQuarterMaxTiles) return;
-	p.kernel = MRT_KERNEL_PACKET_ASM;
+	p.kernel = ctx->two_level ? mrt::MRT_KERNEL_TWO_LEVEL_PACKET : MRT_KERNEL_PACKET_ASM; // (a two-level scene: its packet kernel maps lanes the same way)
 	p.quarter_all = (uint64_t)p.tiles_x * ((p.rows + 7u) / 8u) <= kSixteenthMaxTiles ? 2u : 1u;
 }
 

@@ -305,6 +305,10 @@ def test_small_grids_in_quarter_tiles(built):
         c.d2h(got, d_hits)
         parity.assert_exact(got, want, f"{w}x{h} mrt_cast_tiled")
         c.device_free(d_rays); c.device_free(d_hits)
+    many = synth.incoherent_rays(40000, 24)         # the lane kernel on waves of 1, 2, 4 rays (up to 2^15 rays) and on full ones
+    want_many = osc.trace(many)
+    for n in (1, 2, 63, 64, 65, 255, 1000, 8192, 8193, 16384, 16385, 32768, 32769, 40000):
+        parity.assert_exact(c.cast(many[:n]), want_many[:n], f"{n} incoherent rays")
     inc = synth.incoherent_rays(256 * 64, 23)       # flagged coherent, but not: the device's verdict still routes it to the lane kernel
     parity.assert_exact(c.cast(inc, flags=capi.FLAG_COHERENT), osc.trace(inc), "incoherent rays flagged coherent")
     assert c.stats()["reserved"] == 1

@@ -50,6 +50,31 @@ def _check(c, osc, name):
     assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
 
 
+def test_small_batches_on_a_two_level_scene(built):
+    """Small grids go in pieces of 4 or 16 rays per wave and small incoherent batches on waves of 1, 2 or 4 rays on a two-level
+    scene as on a flat one (api.hip quarter_small_grid, launch_lane): the records are the two-level oracle's at every size,
+    clipped pieces included, for grid casts, batches whose width the device finds, any-hit, and unflagged (sorted) batches."""
+    local, inst = _scene()
+    osc = po.OracleTwoLevelScene(local, inst)
+    c = capi.Context(0)
+    c.upload_two_level_scene(local, inst)
+    for (w, h) in ((16, 12), (61, 37), (128, 128), (200, 160), (333, 201)):
+        cam = capi.camera_look((0, 0, -12), (0, 0.05, 1), w, h, 50.0)
+        rays = po.grid_rays((0, 0, -12), (0, 0.05, 1), w, h, 50.0)
+        want = osc.trace(rays)
+        parity.assert_exact(c.cast_grid(cam, w, h), want, f"two-level {w}x{h} cast_grid")
+        assert c.last_kernel_variant().startswith("trace_two_level_packet_kernel"), c.last_kernel_variant()
+        parity.assert_exact(c.cast(rays, flags=capi.FLAG_COHERENT), want, f"two-level {w}x{h} mrt_cast(COHERENT)")
+        b = c.cast_grid(cam, w, h, mode=capi.MODE_ANY_HIT, flags=capi.FLAG_BOOL_OUT)
+        assert np.array_equal(b.astype(bool), want["prim_id"] >= 0)
+    inc = synth.incoherent_rays(20000, 9)
+    want = osc.trace(inc)
+    for n in (1, 2, 63, 64, 65, 255, 1000, 8192, 8193, 20000):
+        parity.assert_exact(c.cast(inc[:n]), want[:n], f"two-level {n} incoherent rays")
+        parity.assert_exact(c.cast(inc[:n], flags=capi.FLAG_COHERENT), want[:n], f"two-level {n} incoherent rays flagged coherent")
+    c.close()
+
+
 @pytest.mark.parametrize("kernel,stack", [(capi.KERNEL_AUTO, 0), (capi.KERNEL_LANE, 0), (capi.KERNEL_AUTO, 4)])
 def test_two_level_scene_gives_the_oracles_hits(built, kernel, stack):
     """AUTO: the packet form for grids and batches flagged coherent, one lane per ray otherwise (resident waves
