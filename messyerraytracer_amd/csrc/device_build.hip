@@ -534,7 +534,7 @@ __global__ __launch_bounds__(64) void sah_split_kernel(SahNode *nodes, const uin
 	const uint32_t *slot = sh + threadIdx.x * (SAH_SLOT_WORDS + 1);
 	float ext[3];
 	for (int k = 0; k < 3; k++) ext[k] = __fsub_rn(N.mx[k], N.mn[k]);
-	const float rsav = __fdiv_rn(1.0f, __fadd_rn(__fadd_rn(__fmul_rn(ext[0], ext[1]), __fmul_rn(ext[1], ext[2])), __fmul_rn(ext[2], ext[0])));
+	const float inv_area = __fdiv_rn(1.0f, __fadd_rn(__fadd_rn(__fmul_rn(ext[0], ext[1]), __fmul_rn(ext[1], ext[2])), __fmul_rn(ext[2], ext[0])));
 	float split_cost = SAH_FAR;
 	int best_axis = 0, best_pos = 0;
 	for (int a = 0; a < 3; a++) {
@@ -543,7 +543,7 @@ __global__ __launch_bounds__(64) void sah_split_kernel(SahNode *nodes, const uin
 		const uint32_t *ax = slot + a * SAH_BINS * SAH_BIN_WORDS;
 		float lmn[3] = { SAH_FAR, SAH_FAR, SAH_FAR }, lmx[3] = { -SAH_FAR, -SAH_FAR, -SAH_FAR };
 		float rmn[3] = { SAH_FAR, SAH_FAR, SAH_FAR }, rmx[3] = { -SAH_FAR, -SAH_FAR, -SAH_FAR };
-		float anl[SAH_BINS - 1], anr[SAH_BINS - 1];
+		float cost_below[SAH_BINS - 1], cost_above[SAH_BINS - 1];
 		uint32_t ln = 0, rn = 0;
 		for (int i = 0; i < SAH_BINS - 1; i++) {
 			float bmn[3], bmx[3];
@@ -552,15 +552,15 @@ __global__ __launch_bounds__(64) void sah_split_kernel(SahNode *nodes, const uin
 			sah_bin_box(ax + (SAH_BINS - 1 - i) * SAH_BIN_WORDS, bmn, bmx);
 			for (int k = 0; k < 3; k++) { rmn[k] = fminf(rmn[k], bmn[k]); rmx[k] = fmaxf(rmx[k], bmx[k]); }
 			ln += ax[i * SAH_BIN_WORDS + 6]; rn += ax[(SAH_BINS - 1 - i) * SAH_BIN_WORDS + 6];
-			anl[i] = ln == 0u ? SAH_FAR : __fmul_rn(sah_half_area(lmn, lmx), (float)ln);
-			anr[SAH_BINS - 2 - i] = rn == 0u ? SAH_FAR : __fmul_rn(sah_half_area(rmn, rmx), (float)rn);
+			cost_below[i] = ln == 0u ? SAH_FAR : __fmul_rn(sah_half_area(lmn, lmx), (float)ln);
+			cost_above[SAH_BINS - 2 - i] = rn == 0u ? SAH_FAR : __fmul_rn(sah_half_area(rmn, rmx), (float)rn);
 		}
 		for (int i = 0; i < SAH_BINS - 1; i++) {
-			const float c = __fadd_rn(anl[i], anr[i]);
+			const float c = __fadd_rn(cost_below[i], cost_above[i]);
 			if (c < split_cost) { split_cost = c; best_axis = a; best_pos = i; }
 		}
 	}
-	split_cost = __fadd_rn(1.0f, __fmul_rn(__fmul_rn(1.0f, rsav), split_cost));
+	split_cost = __fadd_rn(1.0f, __fmul_rn(__fmul_rn(1.0f, inv_area), split_cost));
 	uint32_t lc = 0;
 	const uint32_t *ax = slot + best_axis * SAH_BINS * SAH_BIN_WORDS;
 	for (int i = 0; i <= best_pos; i++) lc += ax[i * SAH_BIN_WORDS + 6];
