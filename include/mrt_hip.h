@@ -198,7 +198,9 @@ enum {
 
 /* kernel variants (options.kernel); 0 picks the default for the batch */
 enum {
-	MRT_KERNEL_AUTO = 0,
+	MRT_KERNEL_AUTO = 0,    /* by the batch: coherent batches by packets -- from 2^22 rays the 128-ray walk, below it whichever
+	                           of the packet kernels measured fastest on that grid, small grids in pieces of 4 or 16 rays per wave --,
+	                           everything else one lane per ray (resident waves from 2^16 rays, waves of 1 - 4 rays up to 2^15) */
 	MRT_KERNEL_LANE = 1,    /* one lane = one ray, per-lane LDS stack, while-while loop         */
 	MRT_KERNEL_PACKET = 2,  /* one wave = one 64-ray packet, per-wave LDS stack, scalar fetches */
 	/* 3 and 4 were two packet-walk experiments of round 1 (4-wide nodes, two packets per wave); retired, ids not reused */
