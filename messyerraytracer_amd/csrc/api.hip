@@ -410,7 +410,10 @@ int enqueue_cast(mrt_ctx *ctx, const void *rays, void *hits_dev_or_null, uint64_
 	p.out_fmt = out_format(ctx, flags, mode);
 	p.lane_map = mrt::MAP_LINEAR;
 	const uint32_t thr = ctx->opts.sort_threshold ? ctx->opts.sort_threshold : 256u; // MIN_BATCH_FOR_SORTING
-	const bool sort = !(flags & MRT_FLAG_COHERENT) && (count >= thr || (flags & MRT_FLAG_FORCE_SORT));
+	// (a batch of at most 8 192 rays runs one ray per wave in the lane kernel, launch_lane: there is no wave whose rays a sort could
+	// bring together, and its three launches are a third of such a cast's time)
+	const bool one_ray_waves = ctx->opts.kernel == MRT_KERNEL_AUTO && count <= 8192u && !(flags & MRT_FLAG_FORCE_SORT);
+	const bool sort = !(flags & MRT_FLAG_COHERENT) && !one_ray_waves && (count >= thr || (flags & MRT_FLAG_FORCE_SORT));
 	HIP_TRY(ctx, hipEventRecord(ctx->ev[2], ctx->stream));
 	p.kernel = pick_kernel(ctx, !sort && (flags & MRT_FLAG_COHERENT), count);
 	if (sort) {

@@ -116,7 +116,10 @@ def test_g2_g3_small_soup(ctx, soup1k):
         want = osc.trace(rays)
         got = ctx.cast(rays, flags=capi.FLAG_COHERENT)
         parity.assert_exact(got, want, name)
-        got_sorted = ctx.cast(rays)  # >= 256 rays, not coherent: device Morton sort
+        got_plain = ctx.cast(rays)   # not coherent, but at most 8 192 rays: one ray per wave in the lane kernel, no sort
+        assert got_plain.tobytes() == got.tobytes()
+        assert ctx.stats()["last_kernel_launches"] == 1
+        got_sorted = ctx.cast(rays, flags=capi.FLAG_FORCE_SORT)  # the device Morton sort (what batches above 8 192 rays get)
         assert got_sorted.tobytes() == got.tobytes(), "sort on / sort off must give identical results"
         assert ctx.stats()["last_kernel_launches"] == 3
         parity.assert_reference_parity(got["prim_id"], got["t"], g["hits_ref"]["prim_id"], g["hits_ref"]["t"], rays, osc.tris, name)
