@@ -51,7 +51,7 @@ def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=10)  # (the first ~10 casts after start-up run 1-3 % slower while the clocks settle: 3 warm-up steps 8 450-8 500 Mrays/s, 10: 8 560-8 610)
     ap.add_argument("--config", default="C3", help="C2 | C3 (headline; N > 1: one view per GPU) | C5 (one grid, rows sharded over the GPUs)")
     ap.add_argument("--mode", default="cast", choices=["cast", "tiled", "fused"],
                     help="views: cast = mrt_cast on row-major device rays (headline); tiled: mrt_cast_tiled; fused: mrt_cast_grid")
